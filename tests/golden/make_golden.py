@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the REFERENCE itself
+(/root/reference, imported unmodified through tests/golden/_ref_harness.py) on CPU fp32.
+
+    python tests/golden/make_golden.py [case ...]
+
+Runs only in the build container (the reference never travels to the GPU box); the .npz
+files it writes next to itself are data: inputs, seeds, checksums and the reference's
+outputs.  tests/test_oracle_golden.py pins oracle/ttl_oracle.py against them and the
+``-m gpu`` tests compare the HIP path against the same files.
+"""
+import argparse
+import copy
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd"))
+sys.path.insert(0, HERE)
+
+from ttl_amd import synth  # noqa: E402
+from ttl_amd.config import get_config  # noqa: E402
+import _ref_harness as H  # noqa: E402
+
+CIFAR10 = ["airplane", "automobile", "bird", "cat", "deer", "dog", "frog", "horse", "ship", "truck"]
+
+CASES = {
+    # name: (arch, n_views, n_classes, overrides)
+    "tiny_deyo": ("tiny", 8, 10, {}),
+    "tiny_topk": ("tiny", 64, 10, {"filter_ent": 1}),
+    "tiny_steps2": ("tiny", 8, 10, {"tta_steps": 2}),
+    "tiny_r32": ("tiny", 8, 10, {"rank": 32}),
+    "tiny_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
+    "tiny197_deyo": ("tiny197", 8, 10, {}),
+    "b16_n8_k10": ("ViT-B/16", 8, 10, {}),
+    "b16_n64_k200_ent0": ("ViT-B/16", 64, 200, {}),
+    "b16_n64_k200_ent1": ("ViT-B/16", 64, 200, {"filter_ent": 1}),
+}
+
+
+def default_args(**over):
+    """Defaults of the reference CLI (ttl.py:365-424)."""
+    a = argparse.Namespace(
+        arch="ViT-B/16", batch_size=64, lr=5e-3, gpu=0, tpt=True, selection_p=0.1, tta_steps=1,
+        n_ctx=4, ctx_init="a_photo_of_a", cocoop=False, seed=0, layer_range=[9, 11],
+        init_method="xavier", lora_encoder="image", rank=16, deyo_selection=True,
+        aug_type="patch", occlusion_size=112, patch_len=6, row_start=56, column_start=56,
+        deyo_margin=0.5, deyo_margin_e0=0.4, plpd_threshold=0.2, fishers=0, filter_ent=0,
+        filter_plpd=0, reweight_ent=1, reweight_plpd=0)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def build_reference(case):
+    arch, n_views, n_cls, over = CASES[case]
+    cfg = get_config(arch)
+    rank = over.get("rank", 16)
+    cfg = cfg.replace(rank=rank)
+    args = default_args(**over)
+    args.layer_range = [cfg.layer_lo, cfg.layer_hi]
+    args.batch_size = n_views
+    ttl, deyo, cc = H.import_reference(cfg, seed=0)
+    if n_cls == 10:
+        classnames = CIFAR10
+    else:
+        from data.imagnet_prompts import imagenet_classes
+        classnames = list(imagenet_classes[:n_cls])
+    torch.manual_seed(args.seed)
+    # direct ctor so that ``rank`` is honoured (get_coop drops it, Q7); same call otherwise
+    model = cc.ClipTestTimeTuning("cpu", classnames, None, arch="ViT-B/16", n_ctx=args.n_ctx,
+                                  ctx_init=args.ctx_init, layer_range=args.layer_range,
+                                  init_method=args.init_method, lora_encoder="image", rank=rank)
+    # ---- ttl.py:151-163 requires_grad filter (restated: main_worker cannot be called) ----
+    for name, p in model.named_parameters():
+        on = ("image_encoder" in name and ("lora_A" in name or "lora_B" in name)
+              and any(f"layers.{i}." in name for i in range(args.layer_range[0], args.layer_range[1] + 1)))
+        p.requires_grad_(on)
+    # ---- ttl.py:189-220 optimizer groups ----
+    groups = []
+    for i, layer in enumerate(model.image_encoder.vision_model.encoder.layers):
+        if args.layer_range[0] <= i <= args.layer_range[1]:
+            groups += [{"params": layer.self_attn.q_proj.lora_A.parameters()},
+                       {"params": layer.self_attn.q_proj.lora_B.parameters()},
+                       {"params": layer.self_attn.v_proj.lora_A.parameters()},
+                       {"params": layer.self_attn.v_proj.lora_B.parameters()}]
+    opt = torch.optim.AdamW(groups, lr=args.lr)
+    opt_state = copy.deepcopy(opt.state_dict())
+    scaler = torch.cuda.amp.GradScaler(init_scale=1000)   # disabled on CPU (Q14)
+    return cfg, args, ttl, deyo, cc, model, opt, opt_state, scaler, n_views, n_cls
+
+
+def lora_named(model):
+    out = {}
+    for n, p in model.named_parameters():
+        if "image_encoder" in n and ("lora_A" in n or "lora_B" in n):
+            out[n.replace("image_encoder.", "")] = p
+    return out
+
+
+def run_case(case):
+    cfg, args, ttl, deyo, cc, model, opt, opt_state, scaler, N, K = build_reference(case)
+    x = torch.from_numpy(synth.views(cfg, N, seed=7))
+    model.eval()
+    rec = {"logits": []}
+    hook = model.register_forward_hook(lambda m, i, o: rec["logits"].append(o.detach().clone()))
+    taps = {}
+    hooks = []
+    if cfg.width <= 128:
+        vm = model.image_encoder.vision_model
+        first = {"done": False}
+
+        def tap(name):
+            def f(m, i, o):
+                if name not in taps:
+                    taps[name] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+            return f
+        hooks.append(vm.embeddings.register_forward_hook(tap("embed")))
+        hooks.append(vm.pre_layrnorm.register_forward_hook(tap("pre_ln")))
+        for i, l in enumerate(vm.encoder.layers):
+            hooks.append(l.register_forward_hook(tap(f"layer{i}")))
+        hooks.append(vm.post_layernorm.register_forward_hook(tap("pooled")))
+    lora0 = {k: v.detach().clone().numpy() for k, v in lora_named(model).items()}
+    # ---- the per-image sequence of ttl.py:338-352 ----
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    ttl.test_time_tuning(model, x, opt, scaler, args)
+    grads = {k: (p.grad.detach().clone().numpy() if p.grad is not None else None)
+             for k, p in lora_named(model).items()}
+    lora1 = {k: v.detach().clone().numpy() for k, v in lora_named(model).items()}
+    with torch.no_grad():
+        out1 = model(x[:1])
+    hook.remove()
+    for h in hooks:
+        h.remove()
+    tfeat = model.text_features.detach().numpy()
+    z0 = rec["logits"][0]
+    # entropy / selection / loss of the FIRST update, through the reference's own functions
+    Hs = deyo.softmax_entropy(z0)
+    if args.deyo_selection:
+        if args.filter_ent:
+            idx = torch.argsort(Hs, descending=False)[:int(Hs.size()[0] * args.selection_p)]
+        else:
+            idx = torch.where(Hs <= math.log(1000))[0]
+        e = Hs[idx]
+        coeff = args.reweight_ent * (1 / torch.exp(e.clone().detach() - args.deyo_margin_e0))
+        loss = e.mul(coeff).mean(0)
+    else:
+        sel, idx = ttl.select_confident_samples(z0, args.selection_p)
+        coeff = torch.zeros(0)
+        loss = ttl.avg_entropy(sel.float())
+    n_updates = args.tta_steps ** 2 if args.deyo_selection else args.tta_steps
+    assert len(rec["logits"]) == n_updates + 1, (len(rec["logits"]), n_updates)
+    trained = [k for k in lora0 if any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1))]
+    out = dict(
+        arch=cfg.name, rank=cfg.rank, n_views=N, n_classes=K, weight_seed=0, view_seed=7,
+        weights_sha256=synth.checksum(synth.vision_weights(cfg, 0)),
+        x_sha256=synth.checksum([x.numpy()]),
+        objective="deyo" if args.deyo_selection else "tpt",
+        mode="topk" if (args.filter_ent or not args.deyo_selection) else "le_thresh",
+        rho=args.selection_p, margin=args.deyo_margin_e0, n_updates=n_updates, lr=args.lr,
+        text_features=tfeat, logits0=z0.numpy(), H=Hs.numpy(), idx=idx.numpy().astype(np.int64),
+        coeff=coeff.numpy(), loss=np.float32(loss.item()),
+        logits_last=rec["logits"][n_updates - 1].numpy(),
+        logits1=out1.numpy(), top5=torch.topk(out1, min(5, K), dim=1).indices.numpy())
+    for k in (lora0 if cfg.width <= 128 else trained):
+        out["lora0/" + k] = lora0[k]
+    for k in trained:
+        out["grad/" + k] = grads[k]
+        out["lora1/" + k] = lora1[k]
+    for k, v in taps.items():
+        out["tap/" + k] = v.numpy()
+    if cfg.width <= 128 and N <= 8 and cfg.image_size <= 64:
+        out["x"] = x.numpy()
+    path = os.path.join(HERE, case + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{case}: wrote {path} ({os.path.getsize(path)/1e6:.2f} MB) loss={loss.item():.6f} "
+          f"n_sel={idx.numel()} H=[{Hs.min():.3f},{Hs.max():.3f}]")
+
+
+def run_unit():
+    """Known-answer vectors for the loss-side functions and AdamW."""
+    cfg = get_config("tiny")
+    ttl, deyo, cc = H.import_reference(cfg, 0)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for name, (N, K, scale) in {"a": (64, 1000, 3.0), "b": (64, 200, 6.0), "c": (8, 10, 2.0),
+                                "d": (128, 1000, 4.0)}.items():
+        z = torch.randn(N, K, generator=g) * scale
+        if name == "a":  # near-tie across the rho boundary: views 3 and 11 almost equal
+            z[11] = z[3] + 1e-4 * torch.randn(K, generator=g)
+        out[f"{name}/z"] = z.numpy()
+        Hs = deyo.softmax_entropy(z)
+        out[f"{name}/H"] = Hs.numpy()
+        sel, idx = ttl.select_confident_samples(z, 0.1)
+        out[f"{name}/topk_idx"] = idx.numpy().astype(np.int64)
+        if idx.numel():
+            out[f"{name}/avg_entropy"] = np.float32(ttl.avg_entropy(sel.float()).item())
+            zz = z.clone().requires_grad_(True)
+            ttl.avg_entropy(zz[idx].float()).backward()
+            out[f"{name}/tpt_dz"] = zz.grad.numpy()
+        for mode in ("le_thresh", "topk"):
+            zz = z.clone().requires_grad_(True)
+            e = deyo.softmax_entropy(zz)
+            ids = (torch.where(e <= math.log(1000))[0] if mode == "le_thresh"
+                   else torch.argsort(e, descending=False)[:int(N * 0.1)])
+            if ids.numel() == 0:
+                continue
+            e = e[ids]
+            coeff = 1 * (1 / torch.exp(e.clone().detach() - 0.4))
+            loss = e.mul(coeff).mean(0)
+            loss.backward()
+            out[f"{name}/{mode}/idx"] = ids.numpy().astype(np.int64)
+            out[f"{name}/{mode}/loss"] = np.float32(loss.item())
+            out[f"{name}/{mode}/dz"] = zz.grad.numpy()
+    # AdamW: 3 steps on random grads, reference hyper-parameters (ttl.py:218)
+    p = torch.nn.Parameter(torch.randn(16, 96, generator=g) * 0.05)
+    opt = torch.optim.AdamW([p], lr=5e-3)
+    out["adamw/p0"] = p.detach().clone().numpy()
+    for t in range(3):
+        gr = torch.randn(16, 96, generator=g) * (10.0 ** (-t * 2))
+        p.grad = gr.clone()
+        opt.step()
+        out[f"adamw/g{t}"] = gr.numpy()
+        out[f"adamw/p{t + 1}"] = p.detach().clone().numpy()
+    path = os.path.join(HERE, "unit_loss_adamw.npz")
+    np.savez_compressed(path, **out)
+    print("unit: wrote", path, f"({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or (["unit"] + list(CASES))
+    for c in which:
+        if c == "unit":
+            run_unit()
+        else:
+            # one process per case: the reference is patched per geometry at import
+            if len(which) > 1:
+                rc = os.system(f"{sys.executable} {os.path.abspath(__file__)} {c}")
+                if rc:
+                    sys.exit(1)
+            else:
+                run_case(c)

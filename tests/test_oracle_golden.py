@@ -1,0 +1,106 @@
+"""Pins oracle/ttl_oracle.py (the CPU restatement) against fixtures produced by the
+reference itself (tests/golden/make_golden.py).  Runs on CPU; no GPU, no /root/reference."""
+import numpy as np
+import pytest
+
+from oracle import ttl_oracle as O
+from helpers import load_case, episode_kwargs, max_rel, check_lora_step
+
+TINY = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo"]
+
+
+@pytest.fixture(scope="module")
+def unit(golden_dir):
+    return np.load(golden_dir + "/unit_loss_adamw.npz")
+
+
+@pytest.mark.parametrize("s", ["a", "b", "c", "d"])
+def test_softmax_entropy_and_selection(unit, s):
+    z = unit[f"{s}/z"]
+    H = O.softmax_entropy(z)
+    np.testing.assert_allclose(H, unit[f"{s}/H"], rtol=2e-5, atol=2e-6)   # deyo.py:85-90
+    _, idx = O.select_confident_samples(z, 0.1)                            # ttl.py:50-54
+    assert np.array_equal(idx, unit[f"{s}/topk_idx"])                      # bit-exact index set + order
+    if idx.size:
+        assert abs(O.avg_entropy(z[idx]) - unit[f"{s}/avg_entropy"]) <= 2e-5 * max(1, abs(unit[f"{s}/avg_entropy"]))
+        t = O.tpt_loss_and_grad(z, rho=0.1)
+        assert max_rel(t["dz"], unit[f"{s}/tpt_dz"]) < 1e-4
+    else:
+        assert int(z.shape[0] * 0.1) == 0                                  # int(8*0.1)=0 -> empty
+
+
+@pytest.mark.parametrize("s", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("mode", ["le_thresh", "topk"])
+def test_deyo_loss_grad(unit, s, mode):
+    z = unit[f"{s}/z"]
+    L = O.deyo_loss_and_grad(z, mode=mode, rho=0.1, margin=0.4, reweight=1.0)
+    if f"{s}/{mode}/idx" not in unit.files:
+        assert L["loss"] is None and not L["dz"].any()                     # deyo.py:110-113 early return
+        return
+    assert np.array_equal(L["idx"], unit[f"{s}/{mode}/idx"])
+    assert abs(L["loss"] - unit[f"{s}/{mode}/loss"]) <= 1e-5 * abs(unit[f"{s}/{mode}/loss"]) + 1e-7
+    assert max_rel(L["dz"], unit[f"{s}/{mode}/dz"]) < 1e-4
+
+
+def test_adamw_three_steps(unit):
+    p = unit["adamw/p0"]
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for t in range(3):
+        p, m, v = O.adamw_step(p, unit[f"adamw/g{t}"], m, v, t + 1)
+        np.testing.assert_allclose(p, unit[f"adamw/p{t + 1}"], rtol=1e-5, atol=1e-7)
+
+
+def _run_case(name, check_taps):
+    g, cfg, W, x, lora0, tf = load_case(name)
+    if check_taps:
+        taps = {}
+        net = O.VitOracle(cfg, W, lora0, "fp32")
+        z = net.logits(net.forward(x, taps=taps), tf)
+        for k, v in taps.items():
+            if "tap/" + k in g.files:
+                assert max_rel(v, g["tap/" + k]) < 2e-5, k
+    trace = []
+    out = O.episode(cfg, W, lora0, x, tf, trace=trace, **episode_kwargs(g))
+    assert max_rel(out["logits0"], g["logits0"]) < 2e-5
+    np.testing.assert_allclose(trace[0]["H"], g["H"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(trace[0]["idx"], g["idx"])                       # selection: bit-exact
+    assert abs(trace[0]["loss"] - g["loss"]) <= 2e-5 * abs(g["loss"])
+    n_up = int(g["n_updates"])
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert max_rel(trace[-1]["grads"][k[5:]], g[k]) < (1e-4 if n_up == 1 else 2e-2), k
+    for k in g.files:
+        if k.startswith("lora1/"):
+            gr = g["grad/" + k[6:]] if n_up == 1 else None
+            check_lora_step(out["lora"][k[6:]], g[k], gr, float(g["lr"]),
+                            1e-4 if n_up == 1 else 2e-2, k)
+    assert max_rel(trace[-1]["logits"], g["logits_last"]) < (2e-5 if n_up == 1 else 2e-3)
+    assert max_rel(out["logits1"], g["logits1"]) < (1e-4 if n_up == 1 else 2e-3)
+    assert np.array_equal(np.argsort(-out["logits1"], 1)[:, :1], g["top5"][:, :1])
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_episode_tiny(name):
+    _run_case(name, check_taps=True)
+
+
+def test_episode_b16_n8_k10():
+    """BASELINE config 1 (CPU plumbing case): ViT-B/16, r=16, 8 views, K=10."""
+    _run_case("b16_n8_k10", check_taps=False)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1"])
+def test_episode_b16_n64(name):
+    _run_case(name, check_taps=False)
+
+
+def test_bf16_mode_is_close_to_fp32():
+    """The bf16-emulating mode only moves rounding points; it must stay near fp32."""
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    z32 = O.VitOracle(cfg, W, lora0, "fp32")
+    z16 = O.VitOracle(cfg, W, lora0, "bf16")
+    a = z32.logits(z32.forward(x), tf)
+    b = z16.logits(z16.forward(x), tf)
+    assert max_rel(b, a) < 3e-2

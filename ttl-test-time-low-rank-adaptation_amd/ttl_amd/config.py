@@ -1,0 +1,68 @@
+"""Geometry of the CLIP image tower the hot path runs on.
+
+The reference hard-codes ``openai/clip-vit-base-patch16`` (clip/custom_clip.py:581) and
+rank 16 / alpha 32 / targets q_proj,v_proj (clip/custom_clip.py:583-590).  The same
+numbers are the defaults here; ViT-L/14 and reduced test geometries use the same code.
+"""
+from dataclasses import dataclass, asdict
+
+
+@dataclass(frozen=True)
+class VitConfig:
+    name: str = "ViT-B/16"
+    image_size: int = 224
+    patch_size: int = 16
+    width: int = 768          # D
+    heads: int = 12           # H, head dim is always 64 on this path
+    mlp: int = 3072           # F
+    layers: int = 12          # L
+    embed: int = 512          # E (projection dim)
+    ln_eps: float = 1e-5
+    # LoRA (peft LoraConfig at clip/custom_clip.py:583-590)
+    rank: int = 16
+    lora_alpha: float = 32.0
+    # first / last encoder layer whose q/v adapters train (ttl.py:159-161, --layer_range)
+    layer_lo: int = 9
+    layer_hi: int = 11
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def tokens(self) -> int:  # T
+        return self.grid * self.grid + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.width // self.heads
+
+    @property
+    def patch_k(self) -> int:  # 3*P*P
+        return 3 * self.patch_size * self.patch_size
+
+    @property
+    def scaling(self) -> float:  # peft: lora_alpha / r
+        return self.lora_alpha / self.rank
+
+    def replace(self, **kw) -> "VitConfig":
+        d = asdict(self)
+        d.update(kw)
+        return VitConfig(**d)
+
+
+VIT_B16 = VitConfig()
+VIT_L14 = VitConfig(name="ViT-L/14", patch_size=14, width=1024, heads=16, mlp=4096,
+                    layers=24, embed=768, layer_lo=21, layer_hi=23)
+# reduced geometries used by the parity fixtures (tests/golden/make_golden.py)
+VIT_TINY = VitConfig(name="tiny", image_size=64, patch_size=16, width=128, heads=2, mlp=512,
+                     layers=4, embed=64, layer_lo=1, layer_hi=3)
+VIT_TINY197 = VIT_TINY.replace(name="tiny197", image_size=224)
+
+ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197}
+
+
+def get_config(arch: str) -> VitConfig:
+    if arch not in ARCHS:
+        raise ValueError(f"unsupported arch {arch!r}; known: {sorted(ARCHS)}")
+    return ARCHS[arch]

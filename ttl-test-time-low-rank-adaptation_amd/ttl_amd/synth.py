@@ -1,0 +1,119 @@
+"""Deterministic synthetic weights / inputs shared by the golden generator, the oracle
+tests, the GPU parity tests and bench.py.
+
+There is no network on the build or GPU boxes, so the pretrained
+``openai/clip-vit-base-patch16`` checkpoint (clip/custom_clip.py:581) cannot be fetched.
+Every tensor below is a pure function of (seed, tensor name) through numpy's PCG64
+stream, so the golden script can load the *same* weights into the HF ``CLIPModel`` the
+reference builds, and the fixtures only need to store a checksum.
+
+Tensor names are the HF vision-tower names the reference reaches into
+(SURVEY.md appendix B): ``vision_model.embeddings.*``, ``vision_model.pre_layrnorm`` (sic),
+``vision_model.encoder.layers.{i}.*``, ``vision_model.post_layernorm``, ``visual_projection``.
+"""
+import hashlib
+import zlib
+
+import numpy as np
+
+from .config import VitConfig
+
+CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)  # ttl.py:225
+CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)   # ttl.py:226
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([int(seed) & 0x7FFFFFFF, zlib.crc32(name.encode())])
+
+
+def _normal(seed, name, shape, std, mean=0.0):
+    return (_rng(seed, name).standard_normal(shape, dtype=np.float32) * np.float32(std)
+            + np.float32(mean)).astype(np.float32)
+
+
+def vision_weights(cfg: VitConfig, seed: int = 0) -> dict:
+    """fp32 state-dict (numpy) for the image tower + projection + logit_scale.
+
+    Scales are chosen so that attention is peaked (not uniform), LN affine and biases are
+    non-trivial and the residual stream stays O(1) through all layers: a flat synthetic
+    model would hide indexing bugs that a peaked one exposes.
+    """
+    D, F, E, P = cfg.width, cfg.mlp, cfg.embed, cfg.patch_size
+    T = cfg.tokens
+    w = {}
+    pre = "vision_model."
+    w[pre + "embeddings.class_embedding"] = _normal(seed, "cls", (D,), 0.5)
+    w[pre + "embeddings.patch_embedding.weight"] = _normal(seed, "patch", (D, 3, P, P), 0.03)
+    w[pre + "embeddings.position_embedding.weight"] = _normal(seed, "pos", (T, D), 0.1)
+    for nm in ("pre_layrnorm", "post_layernorm"):
+        w[pre + nm + ".weight"] = _normal(seed, nm + ".w", (D,), 0.1, 1.0)
+        w[pre + nm + ".bias"] = _normal(seed, nm + ".b", (D,), 0.05)
+    depth = float(cfg.layers)
+    for i in range(cfg.layers):
+        lp = f"{pre}encoder.layers.{i}."
+        for nm in ("layer_norm1", "layer_norm2"):
+            w[lp + nm + ".weight"] = _normal(seed, f"{i}.{nm}.w", (D,), 0.1, 1.0)
+            w[lp + nm + ".bias"] = _normal(seed, f"{i}.{nm}.b", (D,), 0.05)
+        qk_std = 1.2 / np.sqrt(D)        # q.k/8 has std ~1.4 -> peaked softmax
+        for nm, std in (("q_proj", qk_std), ("k_proj", qk_std),
+                        ("v_proj", 1.0 / np.sqrt(D)),
+                        ("out_proj", 1.0 / np.sqrt(D) / np.sqrt(depth))):
+            w[lp + f"self_attn.{nm}.weight"] = _normal(seed, f"{i}.{nm}.w", (D, D), std)
+            w[lp + f"self_attn.{nm}.bias"] = _normal(seed, f"{i}.{nm}.b", (D,), 0.02)
+        w[lp + "mlp.fc1.weight"] = _normal(seed, f"{i}.fc1.w", (F, D), 1.0 / np.sqrt(D))
+        w[lp + "mlp.fc1.bias"] = _normal(seed, f"{i}.fc1.b", (F,), 0.02)
+        w[lp + "mlp.fc2.weight"] = _normal(seed, f"{i}.fc2.w", (D, F),
+                                           1.0 / np.sqrt(F) / np.sqrt(depth))
+        w[lp + "mlp.fc2.bias"] = _normal(seed, f"{i}.fc2.b", (D,), 0.02)
+    w["visual_projection.weight"] = _normal(seed, "proj", (E, D), 1.0 / np.sqrt(D))
+    w["logit_scale"] = np.array(np.log(100.0), dtype=np.float32)  # pretrained value 4.6052
+    return w
+
+
+def lora_init(cfg: VitConfig, seed: int = 0, targets=("q_proj", "v_proj")) -> dict:
+    """LoRA A (xavier_normal: std = sqrt(2/(D+r)), clip/custom_clip.py:152-153,184-187) and
+    B = 0 (peft default) for every layer, keyed like the reference's parameter names."""
+    D, r = cfg.width, cfg.rank
+    std = np.sqrt(2.0 / (D + r))
+    out = {}
+    for i in range(cfg.layers):
+        for t in targets:
+            base = f"vision_model.encoder.layers.{i}.self_attn.{t}."
+            out[base + "lora_A.default.weight"] = _normal(seed, f"{i}.{t}.A", (r, D), std)
+            out[base + "lora_B.default.weight"] = np.zeros((D, r), dtype=np.float32)
+    return out
+
+
+def views(cfg: VitConfig, n_views: int, seed: int = 0) -> np.ndarray:
+    """[N,3,S,S] fp32 normalised 'uint8 noise' views (synthetic inputs).
+
+    View 0 plays the un-augmented image (ttl.py:327); the others add per-view jitter to a
+    shared low-frequency base so that view entropies differ but are correlated, like
+    crops of one photo."""
+    S = cfg.image_size
+    rng = _rng(seed, f"views{n_views}x{S}")
+    base = rng.integers(0, 256, size=(1, 3, S // 8, S // 8)).astype(np.float32)
+    base = np.repeat(np.repeat(base, 8, axis=2), 8, axis=3)
+    jit = rng.integers(-64, 65, size=(n_views, 3, S, S)).astype(np.float32)
+    scale = rng.uniform(0.6, 1.0, size=(n_views, 1, 1, 1)).astype(np.float32)
+    px = np.clip(base * scale + jit, 0, 255) / np.float32(255.0)
+    px = (px - CLIP_MEAN[None, :, None, None]) / CLIP_STD[None, :, None, None]
+    return np.ascontiguousarray(px.astype(np.float32))
+
+
+def text_features(n_classes: int, embed: int, seed: int = 0) -> np.ndarray:
+    """Unit-norm [K,E] class embeddings standing in for the cached text tower output
+    (clip/custom_clip.py:651-663) when no text encoder is run."""
+    t = _normal(seed, f"text{n_classes}x{embed}", (n_classes, embed), 1.0)
+    t /= np.linalg.norm(t, axis=-1, keepdims=True)
+    return t.astype(np.float32)
+
+
+def checksum(arrs) -> str:
+    """sha256 over a dict (sorted by key) or list of arrays; stored in fixtures."""
+    h = hashlib.sha256()
+    items = sorted(arrs.items()) if isinstance(arrs, dict) else enumerate(arrs)
+    for k, a in items:
+        h.update(str(k).encode())
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
