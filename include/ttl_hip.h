@@ -1,0 +1,184 @@
+/*
+ * ttl_hip.h — C ABI of libttl_hip.so: TTL's per-sample hot path on MI355X (gfx950).
+ *
+ * The reference is pure Python on torch/transformers/peft; the "FFI" a maintainer binds is
+ * ctypes.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference repo root).  Conventions:
+ *   - every pointer is a raw DEVICE pointer unless the comment says host;
+ *   - tensors are dense row-major, fp32 unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing here
+ *     synchronises the host except ttl_load_weight, ttl_ctx_create/destroy, ttl_debug_copy;
+ *   - return value 0 = ok, otherwise a negative TTL_E* code or a positive hipError_t;
+ *     ttl_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ *   - a context is not re-entrant (one shared workspace arena).
+ */
+#ifndef TTL_HIP_H
+#define TTL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTL_OK 0
+#define TTL_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define TTL_ESTATE (-2)   /* call order violated (weights missing, lora not bound, ...) */
+#define TTL_ENOMEM (-3)
+
+/* selection modes of the confidence filter */
+#define TTL_SEL_LE_THRESH 0 /* torch.where(H <= thresh)                deyo.py:107 (default)   */
+#define TTL_SEL_TOPK 1      /* argsort(H)[:int(N*rho)]                 deyo.py:105, ttl.py:52  */
+
+/* Geometry of the image tower (HF CLIPVisionConfig as built at clip/custom_clip.py:581) plus
+ * the peft LoraConfig of clip/custom_clip.py:583-590 and --layer_range (ttl.py:159-161). */
+typedef struct ttl_config {
+    int image_size;   /* 224 */
+    int patch_size;   /* 16 (B/16) or 14 (L/14) */
+    int width;        /* D: 768 / 1024; head dim is fixed at 64 */
+    int heads;        /* H: 12 / 16 */
+    int mlp;          /* F: 3072 / 4096 */
+    int layers;       /* L: 12 / 24 */
+    int embed;        /* E: 512 / 768 */
+    int rank;         /* r: 16 or 32 */
+    float lora_alpha; /* 32 */
+    int layer_lo;     /* first encoder layer whose q/v adapters train */
+    int layer_hi;     /* last one (inclusive) */
+    float ln_eps;     /* 1e-5 */
+    int max_views;    /* capacity N of one ttl_vit_forward call */
+    int max_classes;  /* capacity K */
+} ttl_config;
+
+typedef struct ttl_ctx ttl_ctx;
+
+const char* ttl_last_error(void);
+const char* ttl_version(void);
+
+/* Device memory the context will allocate for `cfg` (weights + activation arena), bytes. */
+size_t ttl_workspace_bytes(const ttl_config* cfg);
+
+/* Replaces model construction + .cuda(): clip/custom_clip.py:570-623, ttl.py:178-179. */
+int ttl_ctx_create(const ttl_config* cfg, ttl_ctx** out);
+void ttl_ctx_destroy(ttl_ctx* ctx);
+
+/* Load one fp32 tensor of the HF vision tower by its state-dict name,
+ * e.g. "vision_model.encoder.layers.3.mlp.fc1.weight", "visual_projection.weight".
+ * `data` may be a host or a device pointer; the call converts to the internal bf16 / fp32
+ * layouts and synchronises.  Replaces CLIPModel.from_pretrained(...).to(device),
+ * clip/custom_clip.py:581. */
+int ttl_load_weight(ttl_ctx* ctx, const char* name, const float* data, size_t count);
+/* 0 once every tensor of the geometry has been loaded, else TTL_ESTATE (message lists one). */
+int ttl_weights_ready(ttl_ctx* ctx);
+
+/* Cached, L2-normalised class embeddings t̂ [K,E] and exp(logit_scale).  Replaces the text
+ * features + logit head inputs of clip/custom_clip.py:651-663,686 (constant per dataset, Q12). */
+int ttl_set_text_features(ttl_ctx* ctx, const float* tfeat, int n_classes, float logit_scale_exp,
+                          void* stream);
+
+/* Bind the trainable LoRA parameters and their gradients: two flat fp32 device buffers laid out
+ * in the order of the 12 param groups of ttl.py:195-213 — for layer = layer_lo..layer_hi:
+ *   q_proj.lora_A [r,D], q_proj.lora_B [D,r], v_proj.lora_A [r,D], v_proj.lora_B [D,r].
+ * n must equal (layer_hi-layer_lo+1) * 4 * r * D.  The caller (torch) owns both buffers. */
+int ttl_bind_lora(ttl_ctx* ctx, float* params, float* grads, size_t n);
+
+/* model(images) — ClipTestTimeTuning.forward/inference, clip/custom_clip.py:665-703, through
+ * VisionEncoder.forward (:62-71) and HF CLIPModel.get_image_features.
+ *   x [N,3,S,S] fp32 NCHW;  logits_out [N,K] fp32;  feats_out [N,E] fp32 or NULL (un-normalised
+ *   image features).  save_for_backward != 0 keeps the activations of the trained layers for
+ *   ttl_vit_backward_lora (the autograd graph of deyo.py:97/186). */
+int ttl_vit_forward(ttl_ctx* ctx, const float* x, int n_views, int save_for_backward,
+                    float* logits_out, float* feats_out, void* stream);
+
+/* softmax_entropy + filter + weighting + mean loss and its gradient w.r.t. the logits:
+ * deyo.py:85-90 (entropy), :103-108 (filter), :175-181 (coeff, loss); autograd of those.
+ *   mode TTL_SEL_LE_THRESH: S = {i : H_i <= thresh}; mode TTL_SEL_TOPK: first int(N*rho) of the
+ *   ascending (stable) argsort of H.   coeff_i = reweight*exp(-(H_i-margin)) (reweight==0: 1).
+ *   H_out [N]; idx_out [N] int64 (first *n_out valid; index order for LE_THRESH, entropy order
+ *   for TOPK — the order torch returns); n_out [1] int32; loss_out [1]; dlogits_out [N,K]
+ *   (zero rows for unselected views; all zero and loss 0 when n == 0, deyo.py:110-113).
+ *   Any output pointer except dlogits_out/n_out may be NULL. */
+int ttl_entropy_select_loss(const float* logits, int n_views, int n_classes, int mode, double rho,
+                            float thresh, float margin, float reweight, float* H_out,
+                            int64_t* idx_out, int* n_out, float* loss_out, float* dlogits_out,
+                            void* stream);
+
+/* TPT objective: select_confident_samples + avg_entropy and its gradient, ttl.py:50-61,87-108.
+ *   reuse_idx != 0: use idx_io[0..*n_io) chosen by an earlier step (ttl.py:97-98). */
+int ttl_tpt_select_loss(const float* logits, int n_views, int n_classes, double rho, int reuse_idx,
+                        float* H_out, int64_t* idx_io, int* n_io, float* loss_out,
+                        float* dlogits_out, void* stream);
+
+/* loss.backward() restricted to what the reference's graph contains: head ->
+ * post-LN -> layers layer_hi..layer_lo, writing dA/dB of q_proj and v_proj into the bound grads
+ * buffer (overwritten, i.e. optimizer.zero_grad() + backward, deyo.py:185-186). */
+int ttl_vit_backward_lora(ttl_ctx* ctx, const float* dlogits, int n_views, void* stream);
+
+/* torch.optim.AdamW.step over one flat buffer (ttl.py:218; deyo.py:187).  `step` is the 1-based
+ * step count of this update.  If `n_selected` (device int32, may be NULL) is 0 the update is
+ * skipped (deyo.py:183: `if final_backward != 0`); a non-finite gradient element also skips
+ * that element's update (GradScaler's skip-on-inf, deyo.py:187, per element). */
+int ttl_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   const int* n_selected, void* stream);
+
+/* Episodic reset: LoRA_AB.reset() (clip/custom_clip.py:202-215) + optimizer.load_state_dict of the
+ * empty state (ttl.py:344): params <- snapshot, exp_avg = exp_avg_sq = 0.  m/v may be NULL. */
+int ttl_lora_reset(float* params, const float* snapshot, float* exp_avg, float* exp_avg_sq,
+                   size_t n, void* stream);
+
+/* One whole test image without host round trips: the body of the loop at ttl.py:338-352.
+ *   reset -> n_updates x [forward(x), loss (objective 0 = DeYO weighted entropy, 1 = TPT),
+ *   LoRA backward, AdamW] -> logits of view 0 with the adapted weights.
+ *   snapshot/exp_avg/exp_avg_sq: flat fp32 buffers shaped like the bound params.
+ *   logits0_out [N,K] (first forward) may be NULL; logits1_out [1,K]. */
+typedef struct ttl_episode_args {
+    const float* x;      /* [N,3,S,S] */
+    int n_views;
+    int n_updates;       /* effective optimizer steps: tta_steps^2 on the DeYO branch (Q6) */
+    int objective;       /* 0 = deyo (deyo.py:92-196), 1 = tpt (ttl.py:87-108) */
+    int mode;            /* TTL_SEL_* (deyo objective) */
+    double rho;          /* selection_p; int(N*rho) is evaluated in double like Python */
+    float thresh, margin, reweight;
+    float lr, beta1, beta2, eps, weight_decay;
+    const float* snapshot;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* logits0_out;
+    float* logits1_out;
+} ttl_episode_args;
+int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
+
+/* ---- kernel-level entry points (used by the unit parity tests; same kernels as above) ---- */
+/* C[M,N] = A[M,K](bf16, lda) * B[N,K]^T(bf16, ldb) -> fp32 C (ldc).  K % 64 == 0, N % 128 == 0. */
+int ttl_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
+                     int K, void* stream);
+/* y = LayerNorm(x) over the last dim (fp32 in, fp32 out, optional mean/rstd [rows]). */
+int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                      float* rstd, int rows, int dim, float eps, void* stream);
+/* fp32 -> bf16 (round to nearest even). */
+int ttl_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream);
+/* softmax(q k^T / 8) v for head dim 64: qkv bf16 [n*T, 3*H*64] (q | k | v), out bf16 [n*T, H*64],
+ * lse fp32 [n,H,T] or NULL. */
+int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n_views, int tokens, int heads,
+                      void* stream);
+/* dq,dk,dv of the above: dqkv bf16 [n*T, ld_dqkv] (dq | dk | dv); need_dk == 0 skips dk. */
+int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                      int ld_dqkv, int n_views, int tokens, int heads, int need_dk, void* stream);
+
+/* Copy an internal buffer to the host (synchronises): name in {"h_in","h_mid","h_out","qkv",
+ * "attn_out","x1","u","lse","dh","features","lora_grads"}; layer indexes encoder layers where it applies. */
+int ttl_debug_copy(ttl_ctx* ctx, const char* name, int layer, void* host_dst, size_t bytes);
+
+/* Per-kernel-class device time of the calls made while profiling is on (HIP events on `stream`).
+ * classes: 0 gemm, 1 attention fwd, 2 attention bwd, 3 layernorm/elementwise, 4 lora, 5 head/loss/opt.
+ * ttl_profile_read synchronises and returns accumulated milliseconds and launch counts. */
+#define TTL_NCLASS 6
+int ttl_profile_enable(ttl_ctx* ctx, int on);
+int ttl_profile_read(ttl_ctx* ctx, double ms[TTL_NCLASS], long long launches[TTL_NCLASS],
+                     double* gemm_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTL_HIP_H */

@@ -1,0 +1,741 @@
+// libttl_hip.so — C ABI (include/ttl_hip.h): context, weight images, and the launch sequences of
+// the hot path.  No torch types; the host side (ttl_amd/_lib.py) binds this with ctypes.
+//
+// HBM layout of a context:
+//   weights  : per layer bf16 [3D][D+64] (Wqkv | LoRA B cols | 0), [D][D] Wo, [F][D] W1, [D][F] W2,
+//              fp32 biases / LN affine; for the trained layers also the dgrad images
+//              bf16 [D][3D+64] (Wqkv^T | LoRA A^T), Wo^T, W1^T [D][F], W2^T [F][D].
+//   stream   : fp32 residual stream [M][D]; trained layers keep h_in and h_mid (LN backward).
+//   saved    : per trained layer bf16 x1ext [M][D+64] (LN1 out | s·U), qkv [M][3D], attn out [M][D],
+//              u [M][F] (fc1 pre-activation), fp32 lse [N][H][T], LN statistics.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ttl_hip.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail((int)e_, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Layer {
+    // forward images
+    bf16_t* wqkv;   // [3D][ldw]
+    float* bqkv;    // [3D]
+    bf16_t* wo;     // [D][D]
+    float* bo;
+    bf16_t* w1;     // [F][D]
+    float* b1;
+    bf16_t* w2;     // [D][F]
+    float* b2;
+    float *ln1g, *ln1b, *ln2g, *ln2b;
+    // dgrad images (trained layers only)
+    bf16_t* wqkvT;  // [D][ldwt]
+    bf16_t* woT;    // [D][D]   (= Wo^T: [in][out] -> rows = in)
+    bf16_t* w1T;    // [D][F]
+    bf16_t* w2T;    // [F][D]
+    bf16_t* acat;   // [2r][D]
+    bf16_t* btcat;  // [2r][D]
+    // saved activations (trained layers only)
+    float* h_in; float* h_mid;
+    bf16_t* x1ext; bf16_t* qkv; bf16_t* attn; bf16_t* u;
+    float* lse; float *mu1, *rs1, *mu2, *rs2;
+    bool trained;
+    unsigned loaded;  // bitmask of loaded tensors
+};
+
+}  // namespace
+
+struct ttl_ctx {
+    ttl_config c;
+    int D, F, H, T, E, L, P, S, G2, r, Kp, ldx, ldw, ldwt, nT;  // nT: trained layers
+    int Mmax;
+    float scaling;
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    std::vector<Layer> layers;
+    // embeddings / head
+    bf16_t* wpatch;  // [D][Kp]
+    float *cls, *pos, *preg, *preb, *postg, *postb;
+    float *wp, *wpT;  // [E][D], [D][E]
+    unsigned head_loaded = 0;
+    // text side
+    float *tfeat, *tfeatT;
+    int K = 0;
+    float scale = 100.f;
+    // lora binding
+    float* lora_p = nullptr; float* lora_g = nullptr; size_t lora_n = 0;
+    // shared activations
+    bf16_t* patches; float* h;  // running residual stream
+    float* h_out[8];             // outputs of trained layers (h_out[i] = input of the next one)
+    bf16_t *x1, *qkv, *attn, *x2, *g;
+    float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits;
+    // backward scratch
+    float *dh, *dh2, *dx; bf16_t *dh16, *dbig, *dattn, *dqkv;
+    float* wg_partial;
+    float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
+    bool saved = false; int saved_n = 0;
+    // profiling
+    bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+};
+
+namespace {
+
+template <typename Tp>
+int dalloc(ttl_ctx* c, Tp** p, size_t count, bool zero = false) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(Tp);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(TTL_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(q, 0, bytes);
+        if (e != hipSuccess) return fail((int)e, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    c->allocs.push_back(q);
+    c->bytes += bytes;
+    *p = (Tp*)q;
+    return 0;
+}
+#define ALLOC(ptr, count, zero)                        \
+    do {                                               \
+        int rc_ = dalloc(c, &(ptr), (size_t)(count), zero); \
+        if (rc_) return rc_;                           \
+    } while (0)
+
+int check_config(const ttl_config* k) {
+    if (!k) return fail(TTL_EINVAL, "null config");
+    if (k->width % 128 || k->width / k->heads != 64 || k->width % k->heads)
+        return fail(TTL_EINVAL, "width must be a multiple of 128 with head_dim 64 (got D=%d H=%d)", k->width, k->heads);
+    if (k->mlp % 128) return fail(TTL_EINVAL, "mlp must be a multiple of 128");
+    if (k->rank != 16 && k->rank != 32) return fail(TTL_EINVAL, "rank must be 16 or 32 (got %d)", k->rank);
+    if (k->image_size % k->patch_size || k->image_size % 8) return fail(TTL_EINVAL, "bad image/patch size");
+    if (k->layer_lo < 0 || k->layer_hi >= k->layers || k->layer_lo > k->layer_hi || k->layer_hi - k->layer_lo >= 8)
+        return fail(TTL_EINVAL, "bad layer range [%d,%d]", k->layer_lo, k->layer_hi);
+    if (k->layer_hi != k->layers - 1)
+        return fail(TTL_EINVAL, "layer_hi must be the last encoder layer (%d); got %d", k->layers - 1, k->layer_hi);
+    int T = (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
+    if (T > 288) return fail(TTL_EINVAL, "token count %d > 288 unsupported", T);
+    if (k->max_views < 1 || k->max_classes < 1 || k->embed < 1 || k->embed > 4096) return fail(TTL_EINVAL, "bad capacities");
+    return 0;
+}
+
+void set_geometry(ttl_ctx* c, const ttl_config* k) {
+    c->c = *k;
+    c->D = k->width; c->F = k->mlp; c->H = k->heads; c->E = k->embed; c->L = k->layers; c->P = k->patch_size;
+    c->S = k->image_size; c->G2 = (c->S / c->P) * (c->S / c->P); c->T = c->G2 + 1; c->r = k->rank;
+    c->Kp = round_up(3 * c->P * c->P, 64);
+    c->ldx = c->D + 64;        // x1ext: D | 2r LoRA cols | zero pad
+    c->ldw = c->D + 64;        // wqkv rows
+    c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
+    c->nT = k->layer_hi - k->layer_lo + 1;
+    c->Mmax = k->max_views * c->T;
+    c->scaling = k->lora_alpha / (float)k->rank;
+}
+
+// ---- profiling helper: bracket a launch group with events on the stream
+struct Prof {
+    ttl_ctx* c; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    Prof(ttl_ctx* c_, int cls_, hipStream_t s_) : c(c_), cls(cls_), s(s_) {
+        if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~Prof() {
+        if (c->prof) { hipEventRecord(b, s); c->prof_events.push_back({cls, {a, b}}); }
+    }
+};
+
+int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a, hipStream_t s) {
+    Prof p(c, 0, s);
+    if (c->prof) c->gemm_flops += 2.0 * a.M * a.N * a.K;
+    HIP_TRY(launch_gemm(epi, a, s));
+    return 0;
+}
+
+enum { W_QW = 1, W_QB = 2, W_KW = 4, W_KB = 8, W_VW = 16, W_VB = 32, W_OW = 64, W_OB = 128, W_1W = 256, W_1B = 512,
+       W_2W = 1024, W_2B = 2048, W_L1G = 4096, W_L1B = 8192, W_L2G = 16384, W_L2B = 32768, W_ALL = 65535 };
+enum { HW_CLS = 1, HW_PATCH = 2, HW_POS = 4, HW_PREG = 8, HW_PREB = 16, HW_POSTG = 32, HW_POSTB = 64, HW_PROJ = 128, HW_ALL = 255 };
+
+}  // namespace
+
+extern "C" {
+
+const char* ttl_last_error(void) { return g_err; }
+const char* ttl_version(void) { return "ttl_hip 0.1 (gfx950)"; }
+
+size_t ttl_workspace_bytes(const ttl_config* k) {
+    if (check_config(k)) return 0;
+    ttl_ctx t; set_geometry(&t, k);
+    size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nT, N = k->max_views;
+    size_t w = L * (3 * D * t.ldw + D * D + 2 * D * F) * 2 + nT * (D * t.ldwt + D * D + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4;
+    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * D + M * F) * 2 +
+                 (M * D + M * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * D + M * F + M * D + M * t.ldwt) * 2 +
+                 (size_t)lora_wgrad_chunks((int)M) * 4 * t.r * D * 4;
+    return w + act;
+}
+
+int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
+    if (!out) return fail(TTL_EINVAL, "null out");
+    *out = nullptr;
+    int rc = check_config(k);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(e != hipSuccess ? (int)e : TTL_ESTATE, "no HIP device available (%s)", hipGetErrorString(e));
+    ttl_ctx* c = new ttl_ctx();
+    set_geometry(c, k);
+    const size_t D = c->D, F = c->F, M = c->Mmax, E = c->E, N = k->max_views, T = c->T, H = c->H, r = c->r;
+    struct Guard { ttl_ctx* c; bool ok = false; ~Guard() { if (!ok) ttl_ctx_destroy(c); } } guard{c};
+    c->layers.resize(c->L);
+    for (int i = 0; i < c->L; ++i) {
+        Layer& l = c->layers[i];
+        memset(&l, 0, sizeof l);
+        l.trained = (i >= k->layer_lo && i <= k->layer_hi);
+        ALLOC(l.wqkv, 3 * D * c->ldw, true); ALLOC(l.bqkv, 3 * D, true);
+        ALLOC(l.wo, D * D, false); ALLOC(l.bo, D, true);
+        ALLOC(l.w1, F * D, false); ALLOC(l.b1, F, true);
+        ALLOC(l.w2, D * F, false); ALLOC(l.b2, D, true);
+        ALLOC(l.ln1g, D, true); ALLOC(l.ln1b, D, true); ALLOC(l.ln2g, D, true); ALLOC(l.ln2b, D, true);
+        if (l.trained) {
+            ALLOC(l.wqkvT, D * c->ldwt, true); ALLOC(l.woT, D * D, false); ALLOC(l.w1T, D * F, false); ALLOC(l.w2T, F * D, false);
+            ALLOC(l.acat, 2 * r * D, true); ALLOC(l.btcat, 2 * r * D, true);
+            ALLOC(l.h_mid, M * D, false);  // h_in is a pointer into the stream buffers
+            ALLOC(l.x1ext, M * c->ldx, true); ALLOC(l.qkv, M * 3 * D, false); ALLOC(l.attn, M * D, false); ALLOC(l.u, M * F, false);
+            ALLOC(l.lse, N * H * T, false);
+            ALLOC(l.mu1, M, false); ALLOC(l.rs1, M, false); ALLOC(l.mu2, M, false); ALLOC(l.rs2, M, false);
+        }
+    }
+    ALLOC(c->wpatch, D * c->Kp, true);
+    ALLOC(c->cls, D, true); ALLOC(c->pos, T * D, true);
+    ALLOC(c->preg, D, true); ALLOC(c->preb, D, true); ALLOC(c->postg, D, true); ALLOC(c->postb, D, true);
+    ALLOC(c->wp, E * D, true); ALLOC(c->wpT, D * E, true);
+    ALLOC(c->tfeat, (size_t)k->max_classes * E, true); ALLOC(c->tfeatT, (size_t)k->max_classes * E, true);
+    ALLOC(c->patches, N * c->G2 * c->Kp, true);
+    ALLOC(c->h, M * D, false);
+    for (int i = 0; i < c->nT; ++i) ALLOC(c->h_out[i], M * D, false);
+    ALLOC(c->x1, M * D, false); ALLOC(c->qkv, M * 3 * D, false); ALLOC(c->attn, M * D, false);
+    ALLOC(c->x2, M * D, false); ALLOC(c->g, M * F, false);
+    ALLOC(c->cls_mean, N, false); ALLOC(c->cls_rstd, N, false); ALLOC(c->ycls, N * D, false); ALLOC(c->feat, N * E, false);
+    ALLOC(c->logits, N * k->max_classes, false); ALLOC(c->dlogits, N * k->max_classes, false);
+    ALLOC(c->dh, M * D, false); ALLOC(c->dh2, M * D, false); ALLOC(c->dx, M * D, false);
+    ALLOC(c->dh16, M * D, false); ALLOC(c->dbig, M * F, false); ALLOC(c->dattn, M * D, false);
+    ALLOC(c->dqkv, M * c->ldwt, true);
+    ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 4 * r * D, false);
+    ALLOC(c->loss_scratch, 4 * N + 3 * (size_t)k->max_classes + 16, true);
+    ALLOC(c->idx_buf, N, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, N, true);
+    guard.ok = true;
+    *out = c;
+    return 0;
+}
+
+void ttl_ctx_destroy(ttl_ctx* c) {
+    if (!c) return;
+    hipDeviceSynchronize();
+    for (auto& pe : c->prof_events) { hipEventDestroy(pe.second.first); hipEventDestroy(pe.second.second); }
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------ weights
+static int upload(ttl_ctx* c, const float* data, size_t count, float** tmp) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(float));
+    if (e != hipSuccess) return fail(TTL_ENOMEM, "staging hipMalloc failed: %s", hipGetErrorString(e));
+    e = hipMemcpy(q, data, count * sizeof(float), hipMemcpyDefault);
+    if (e != hipSuccess) { hipFree(q); return fail((int)e, "weight copy failed: %s", hipGetErrorString(e)); }
+    *tmp = (float*)q;
+    return 0;
+}
+
+int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t count) {
+    if (!c || !name || !data) return fail(TTL_EINVAL, "null argument");
+    const size_t D = c->D, F = c->F, E = c->E, T = c->T;
+    float* tmp = nullptr;
+    int rc = 0;
+    hipStream_t s = nullptr;
+#define NEED(n)                                                                                         \
+    if (count != (size_t)(n)) return fail(TTL_EINVAL, "%s: expected %zu elements, got %zu", name, (size_t)(n), count)
+#define F32COPY(dst) HIP_TRY(hipMemcpy((dst), data, count * sizeof(float), hipMemcpyDefault))
+    std::string nm(name);
+    int li = -1;
+    const char* lp = strstr(name, "encoder.layers.");
+    if (lp) {
+        li = atoi(lp + 15);
+        if (li < 0 || li >= c->L) return fail(TTL_EINVAL, "%s: layer out of range", name);
+        Layer& l = c->layers[li];
+        const char* tail = strchr(lp + 15, '.');
+        if (!tail) return fail(TTL_EINVAL, "bad name %s", name);
+        std::string t(tail + 1);
+        auto proj_w = [&](int which, unsigned bit) -> int {  // q/k/v weight [D][D] -> rows which*D.. of wqkv (+ transposed image)
+            NEED(D * D);
+            if ((rc = upload(c, data, count, &tmp))) return rc;
+            hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)D, l.wqkv + (size_t)which * D * c->ldw, c->ldw, s);
+            if (e == hipSuccess && l.trained) e = launch_transpose_f32_bf16(tmp, (int)D, (int)D, l.wqkvT + (size_t)which * D, c->ldwt, s);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            hipFree(tmp);
+            if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
+            l.loaded |= bit;
+            return 0;
+        };
+        auto plain_w = [&](bf16_t* dst, bf16_t* dstT, size_t rows, size_t cols, unsigned bit) -> int {
+            NEED(rows * cols);
+            if ((rc = upload(c, data, count, &tmp))) return rc;
+            hipError_t e = launch_cast_f32_bf16(tmp, dst, count, s);
+            if (e == hipSuccess && dstT) e = launch_transpose_f32_bf16(tmp, (int)rows, (int)cols, dstT, (int)rows, s);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            hipFree(tmp);
+            if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
+            l.loaded |= bit;
+            return 0;
+        };
+        if (t == "self_attn.q_proj.weight") return proj_w(0, W_QW);
+        if (t == "self_attn.k_proj.weight") return proj_w(1, W_KW);
+        if (t == "self_attn.v_proj.weight") return proj_w(2, W_VW);
+        if (t == "self_attn.q_proj.bias") { NEED(D); F32COPY(l.bqkv); l.loaded |= W_QB; return 0; }
+        if (t == "self_attn.k_proj.bias") { NEED(D); F32COPY(l.bqkv + D); l.loaded |= W_KB; return 0; }
+        if (t == "self_attn.v_proj.bias") { NEED(D); F32COPY(l.bqkv + 2 * D); l.loaded |= W_VB; return 0; }
+        if (t == "self_attn.out_proj.weight") return plain_w(l.wo, l.trained ? l.woT : nullptr, D, D, W_OW);
+        if (t == "self_attn.out_proj.bias") { NEED(D); F32COPY(l.bo); l.loaded |= W_OB; return 0; }
+        if (t == "mlp.fc1.weight") return plain_w(l.w1, l.trained ? l.w1T : nullptr, F, D, W_1W);
+        if (t == "mlp.fc1.bias") { NEED(F); F32COPY(l.b1); l.loaded |= W_1B; return 0; }
+        if (t == "mlp.fc2.weight") return plain_w(l.w2, l.trained ? l.w2T : nullptr, D, F, W_2W);
+        if (t == "mlp.fc2.bias") { NEED(D); F32COPY(l.b2); l.loaded |= W_2B; return 0; }
+        if (t == "layer_norm1.weight") { NEED(D); F32COPY(l.ln1g); l.loaded |= W_L1G; return 0; }
+        if (t == "layer_norm1.bias") { NEED(D); F32COPY(l.ln1b); l.loaded |= W_L1B; return 0; }
+        if (t == "layer_norm2.weight") { NEED(D); F32COPY(l.ln2g); l.loaded |= W_L2G; return 0; }
+        if (t == "layer_norm2.bias") { NEED(D); F32COPY(l.ln2b); l.loaded |= W_L2B; return 0; }
+        return fail(TTL_EINVAL, "unknown layer tensor %s", name);
+    }
+    if (nm == "vision_model.embeddings.class_embedding") { NEED(D); F32COPY(c->cls); c->head_loaded |= HW_CLS; return 0; }
+    if (nm == "vision_model.embeddings.position_embedding.weight") { NEED(T * D); F32COPY(c->pos); c->head_loaded |= HW_POS; return 0; }
+    if (nm == "vision_model.embeddings.patch_embedding.weight") {
+        size_t kk = 3 * (size_t)c->P * c->P;
+        NEED(D * kk);
+        if ((rc = upload(c, data, count, &tmp))) return rc;
+        hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)kk, c->wpatch, c->Kp, s);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        hipFree(tmp);
+        if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
+        c->head_loaded |= HW_PATCH;
+        return 0;
+    }
+    if (nm == "vision_model.pre_layrnorm.weight") { NEED(D); F32COPY(c->preg); c->head_loaded |= HW_PREG; return 0; }
+    if (nm == "vision_model.pre_layrnorm.bias") { NEED(D); F32COPY(c->preb); c->head_loaded |= HW_PREB; return 0; }
+    if (nm == "vision_model.post_layernorm.weight") { NEED(D); F32COPY(c->postg); c->head_loaded |= HW_POSTG; return 0; }
+    if (nm == "vision_model.post_layernorm.bias") { NEED(D); F32COPY(c->postb); c->head_loaded |= HW_POSTB; return 0; }
+    if (nm == "visual_projection.weight") {
+        NEED(E * D);
+        F32COPY(c->wp);
+        std::vector<float> host(count), tr(count);
+        HIP_TRY(hipMemcpy(host.data(), c->wp, count * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < E; ++e)
+            for (size_t d = 0; d < D; ++d) tr[d * E + e] = host[e * D + d];
+        HIP_TRY(hipMemcpy(c->wpT, tr.data(), count * sizeof(float), hipMemcpyHostToDevice));
+        c->head_loaded |= HW_PROJ;
+        return 0;
+    }
+    return fail(TTL_EINVAL, "unknown tensor %s", name);
+#undef NEED
+#undef F32COPY
+}
+
+int ttl_weights_ready(ttl_ctx* c) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    if (c->head_loaded != HW_ALL) return fail(TTL_ESTATE, "embedding/head tensors missing (mask 0x%x of 0x%x)", c->head_loaded, HW_ALL);
+    for (int i = 0; i < c->L; ++i)
+        if (c->layers[i].loaded != W_ALL) return fail(TTL_ESTATE, "layer %d tensors missing (mask 0x%x)", i, c->layers[i].loaded);
+    return 0;
+}
+
+int ttl_set_text_features(ttl_ctx* c, const float* tfeat, int K, float scale, void* stream) {
+    if (!c || !tfeat) return fail(TTL_EINVAL, "null argument");
+    if (K < 1 || K > c->c.max_classes) return fail(TTL_EINVAL, "n_classes %d outside [1,%d]", K, c->c.max_classes);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(c->tfeat, tfeat, (size_t)K * c->E * sizeof(float), hipMemcpyDefault, s));
+    // transposed copy [E][K] for coalesced logits; small, do it through the host once per dataset
+    std::vector<float> host((size_t)K * c->E), tr((size_t)K * c->E);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(host.data(), c->tfeat, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int k = 0; k < K; ++k)
+        for (int e = 0; e < c->E; ++e) tr[(size_t)e * K + k] = host[(size_t)k * c->E + e];
+    HIP_TRY(hipMemcpy(c->tfeatT, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->K = K;
+    c->scale = scale;
+    return 0;
+}
+
+int ttl_bind_lora(ttl_ctx* c, float* params, float* grads, size_t n) {
+    if (!c || !params || !grads) return fail(TTL_EINVAL, "null argument");
+    size_t want = (size_t)c->nT * 4 * c->r * c->D;
+    if (n != want) return fail(TTL_EINVAL, "lora buffer has %zu elements, geometry needs %zu", n, want);
+    c->lora_p = params; c->lora_g = grads; c->lora_n = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ forward
+static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* logits) {
+    HeadArgs a;
+    a.h = h; a.T = c->T; a.D = c->D; a.E = c->E; a.K = c->K;
+    a.ln_g = c->postg; a.ln_b = c->postb; a.eps = c->c.ln_eps;
+    a.WpT = c->wpT; a.Wp = c->wp; a.tfeat = c->tfeat; a.tfeatT = c->tfeatT; a.scale = c->scale;
+    a.cls_mean = c->cls_mean; a.cls_rstd = c->cls_rstd; a.y = c->ycls; a.f = c->feat; a.logits = logits; a.feats_out = feats_out;
+    return a;
+}
+
+static int lora_refresh(ttl_ctx* c, hipStream_t s) {
+    Prof p(c, 4, s);
+    const size_t per = (size_t)c->r * c->D;
+    for (int i = 0; i < c->nT; ++i) {
+        Layer& l = c->layers[c->c.layer_lo + i];
+        const float* base = c->lora_p + (size_t)i * 4 * per;
+        HIP_TRY(launch_lora_refresh(base, base + per, base + 2 * per, base + 3 * per, c->D, c->r, l.wqkv, c->ldw, l.wqkvT, c->ldwt,
+                                    l.acat, l.btcat, s));
+    }
+    return 0;
+}
+
+int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_out, float* feats_out, void* stream) {
+    if (!c || !x) return fail(TTL_EINVAL, "null argument");
+    if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
+    if (c->K < 1) return fail(TTL_ESTATE, "ttl_set_text_features has not been called");
+    if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
+    int rc = ttl_weights_ready(c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H;
+    if ((rc = lora_refresh(c, s))) return rc;
+    // patch embedding: im2col -> GEMM (+pos) ; CLS rows
+    {
+        Prof p(c, 3, s);
+        HIP_TRY(launch_im2col(x, c->patches, n, c->S, c->P, c->Kp, s));
+        HIP_TRY(launch_cls_rows(c->h, c->cls, c->pos, n, T, D, s));
+    }
+    {
+        GemmArgs a = {};
+        a.A = c->patches; a.lda = c->Kp; a.B = c->wpatch; a.ldb = c->Kp; a.M = n * c->G2; a.N = D; a.K = c->Kp;
+        a.C = c->h; a.ldc = D; a.pos = c->pos; a.G2 = c->G2; a.T = T;
+        if ((rc = gemm(c, EPI_PATCH, a, s))) return rc;
+    }
+    float* h = c->h;
+    {
+        Prof p(c, 3, s);
+        HIP_TRY(launch_layernorm(h, D, c->preg, c->preb, h, nullptr, 0, nullptr, nullptr, M, D, c->c.ln_eps, s));
+    }
+    for (int i = 0; i < c->L; ++i) {
+        Layer& l = c->layers[i];
+        const bool tr = l.trained;          // LoRA path active (B == 0 forever in the other layers, Q10)
+        const bool sv = tr && save;
+        bf16_t* x1 = tr ? l.x1ext : c->x1;
+        const int ldx1 = tr ? c->ldx : D;
+        bf16_t* qkv = tr ? l.qkv : c->qkv;
+        bf16_t* att = tr ? l.attn : c->attn;
+        float* h_in = h;  // trained layers write h_mid / h_out to fresh buffers, so h_in survives for LN1 backward
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_layernorm(h_in, D, l.ln1g, l.ln1b, nullptr, x1, ldx1, sv ? l.mu1 : nullptr, sv ? l.rs1 : nullptr, M, D, c->c.ln_eps, s));
+        }
+        if (tr) {
+            Prof p(c, 4, s);
+            HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
+        }
+        {
+            GemmArgs a = {};
+            a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = tr ? D + 64 : D;
+            a.C = qkv; a.ldc = 3 * D; a.bias = l.bqkv;
+            if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+        }
+        {
+            Prof p(c, 1, s);
+            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s));
+        }
+        float* h_mid = tr ? l.h_mid : h_in;
+        {
+            GemmArgs a = {};
+            a.A = att; a.lda = D; a.B = l.wo; a.ldb = D; a.M = M; a.N = D; a.K = D;
+            a.C = h_mid; a.ldc = D; a.bias = l.bo; a.resid = h_in; a.ldr = D;
+            if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
+        }
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_layernorm(h_mid, D, l.ln2g, l.ln2b, nullptr, c->x2, D, sv ? l.mu2 : nullptr, sv ? l.rs2 : nullptr, M, D, c->c.ln_eps, s));
+        }
+        {
+            GemmArgs a = {};
+            a.A = c->x2; a.lda = D; a.B = l.w1; a.ldb = D; a.M = M; a.N = F; a.K = D;
+            a.C = c->g; a.ldc = F; a.bias = l.b1; a.C2 = sv ? l.u : nullptr; a.ldc2 = F;
+            if ((rc = gemm(c, EPI_GELU, a, s))) return rc;
+        }
+        float* h_next = tr ? c->h_out[i - c->c.layer_lo] : h_mid;
+        {
+            GemmArgs a = {};
+            a.A = c->g; a.lda = F; a.B = l.w2; a.ldb = F; a.M = M; a.N = D; a.K = F;
+            a.C = h_next; a.ldc = D; a.bias = l.b2; a.resid = h_mid; a.ldr = D;
+            if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
+        }
+        if (tr) l.h_in = h_in;  // pointer only: h_in stays untouched from here on (the stream moved on)
+        h = h_next;
+    }
+    {
+        Prof p(c, 5, s);
+        HeadArgs a = head_args(c, h, feats_out, c->logits);
+        HIP_TRY(launch_head_fwd(a, n, s));
+        if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, c->logits, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    c->saved = save != 0;
+    c->saved_n = n;
+    return 0;
+}
+
+int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double rho, float thresh, float margin, float reweight,
+                            float* H_out, int64_t* idx_out, int* n_out, float* loss_out, float* dlogits_out, void* stream) {
+    if (!logits || !dlogits_out || !n_out) return fail(TTL_EINVAL, "null argument");
+    if (N < 1 || K < 1) return fail(TTL_EINVAL, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;
+    size_t cnt = 4 * (size_t)N + 3 * (size_t)K + 16;
+    HIP_TRY(hipMallocAsync((void**)&scratch, cnt * sizeof(float), s));
+    hipError_t e = launch_entropy_loss(logits, N, K, 0, mode, rho, thresh, margin, reweight, 0, H_out, (long long*)idx_out, n_out,
+                                       loss_out, dlogits_out, scratch, s);
+    hipFreeAsync(scratch, s);
+    HIP_TRY(e);
+    return 0;
+}
+
+int ttl_tpt_select_loss(const float* logits, int N, int K, double rho, int reuse_idx, float* H_out, int64_t* idx_io, int* n_io,
+                        float* loss_out, float* dlogits_out, void* stream) {
+    if (!logits || !dlogits_out || !n_io || !idx_io) return fail(TTL_EINVAL, "null argument");
+    if (N < 1 || K < 1) return fail(TTL_EINVAL, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;
+    size_t cnt = 4 * (size_t)N + 3 * (size_t)K + 16;
+    HIP_TRY(hipMallocAsync((void**)&scratch, cnt * sizeof(float), s));
+    hipError_t e = launch_entropy_loss(logits, N, K, 1, TTL_SEL_TOPK, rho, 0.f, 0.f, 0.f, reuse_idx, H_out, (long long*)idx_io, n_io,
+                                       loss_out, dlogits_out, scratch, s);
+    hipFreeAsync(scratch, s);
+    HIP_TRY(e);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ backward
+int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
+    if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");
+    if (!c->saved || c->saved_n != n) return fail(TTL_ESTATE, "no saved forward for %d views (call ttl_vit_forward with save_for_backward)", n);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H, r = c->r;
+    int rc;
+    float* dh = c->dh;      // gradient w.r.t. the residual stream at the current depth
+    float* dh_alt = c->dh2;
+    {
+        Prof p(c, 5, s);
+        HIP_TRY(launch_fill_zero(dh, (size_t)M * D * sizeof(float), s));
+        HIP_TRY(launch_fill_zero(c->dh16, (size_t)M * D * sizeof(bf16_t), s));
+        HeadArgs a = head_args(c, c->h_out[c->nT - 1], nullptr, c->logits);
+        HIP_TRY(launch_head_bwd(a, dlogits, dh, c->dh16, n, s));
+    }
+    const size_t per = (size_t)r * D;
+    for (int i = c->c.layer_hi; i >= c->c.layer_lo; --i) {
+        Layer& l = c->layers[i];
+        const bool first = (i == c->c.layer_lo);
+        // ---- MLP: dg = dh·W2 (∘ gelu'(u)) ; dx2 = du·W1 ; dh_mid = dh + LN2^T(dx2)
+        {
+            GemmArgs a = {};
+            a.A = c->dh16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = M; a.N = F; a.K = D;
+            a.C = c->dbig; a.ldc = F; a.aux = l.u; a.ldaux = F;
+            if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
+        }
+        {
+            GemmArgs a = {};
+            a.A = c->dbig; a.lda = F; a.B = l.w1T; a.ldb = F; a.M = M; a.N = D; a.K = F;
+            a.C = c->dx; a.ldc = D;
+            if ((rc = gemm(c, EPI_F32, a, s))) return rc;
+        }
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_layernorm_bwd(c->dx, l.h_mid, l.mu2, l.rs2, l.ln2g, dh, dh_alt, c->dh16, M, D, s));
+        }
+        float* dhm = dh_alt;  // d/d h_mid
+        // ---- attention output projection: do = dh_mid·Wo
+        {
+            GemmArgs a = {};
+            a.A = c->dh16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = M; a.N = D; a.K = D;
+            a.C = c->dattn; a.ldc = D;
+            if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+        }
+        {
+            Prof p(c, 2, s);
+            HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
+        }
+        // ---- LoRA: dU = s·[dq·B_q | dv·B_v] ; dA, dB
+        {
+            Prof p(c, 4, s);
+            HIP_TRY(launch_lora_skinny(c->dqkv, c->ldwt, 0, 2 * D, l.btcat, D, r, c->scaling, c->dqkv + 3 * D, c->ldwt, M, s));
+            float* g = c->lora_g + (size_t)(i - c->c.layer_lo) * 4 * per;
+            HIP_TRY(launch_lora_wgrad(l.x1ext, c->ldx, c->dqkv, c->ldwt, M, D, r, c->wg_partial, g, g + per, g + 2 * per, g + 3 * per, s));
+        }
+        if (first) break;
+        // ---- dx1 = [dq dk dv | dU]·[Wqkv | A]  ; dh_in = dh_mid + LN1^T(dx1)
+        {
+            GemmArgs a = {};
+            a.A = c->dqkv; a.lda = c->ldwt; a.B = l.wqkvT; a.ldb = c->ldwt; a.M = M; a.N = D; a.K = c->ldwt;
+            a.C = c->dx; a.ldc = D;
+            if ((rc = gemm(c, EPI_F32, a, s))) return rc;
+        }
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s));
+        }
+        // dh now holds d/d h_in of layer i == d/d h_out of layer i-1
+    }
+    return 0;
+}
+
+int ttl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                   const int* nsel, void* stream) {
+    if (!p || !g || !m || !v) return fail(TTL_EINVAL, "null argument");
+    if (step < 1) return fail(TTL_EINVAL, "step must be >= 1");
+    HIP_TRY(launch_adamw(p, g, m, v, n, lr, b1, b2, eps, wd, step, nsel, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, void* stream) {
+    if (!p || !snap) return fail(TTL_EINVAL, "null argument");
+    HIP_TRY(launch_lora_reset(p, snap, m, v, n, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
+    if (!c || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
+    if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
+    for (int u = 0; u < a->n_updates; ++u) {
+        if ((rc = ttl_vit_forward(c, a->x, a->n_views, 1, (u == 0) ? a->logits0_out : nullptr, nullptr, stream))) return rc;
+        {
+            Prof p(c, 5, s);
+            HIP_TRY(launch_entropy_loss(c->logits, a->n_views, c->K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
+                                        (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf, c->dlogits,
+                                        c->loss_scratch, s));
+        }
+        if ((rc = ttl_vit_backward_lora(c, c->dlogits, a->n_views, stream))) return rc;
+        {
+            Prof p(c, 5, s);
+            HIP_TRY(launch_adamw(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                 a->weight_decay, u + 1, c->n_buf, s));
+        }
+    }
+    return ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------ kernel-level entry points
+int ttl_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    hipError_t e = launch_gemm(EPI_F32, a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));
+    return 0;
+}
+
+int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int dim,
+                      float eps, void* stream) {
+    HIP_TRY(launch_layernorm(x, dim, gamma, beta, y, nullptr, 0, mean, rstd, rows, dim, eps, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream) {
+    HIP_TRY(launch_cast_f32_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n, int T, int H, void* stream) {
+    HIP_TRY(launch_attention_fwd((const bf16_t*)qkv, 3 * H * 64, (bf16_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int ld_dqkv, int n, int T,
+                      int H, int need_dk, void* stream) {
+    HIP_TRY(launch_attention_bwd((const bf16_t*)qkv, 3 * H * 64, (const bf16_t*)out, (const bf16_t*)dout, H * 64, lse, (bf16_t*)dqkv,
+                                 ld_dqkv, n, T, H, need_dk, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t bytes) {
+    if (!c || !name || !dst) return fail(TTL_EINVAL, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    const void* src = nullptr;
+    size_t have = 0;
+    const size_t M = (size_t)c->saved_n * c->T, D = c->D, F = c->F;
+    std::string nm(name);
+    bool tr = layer >= c->c.layer_lo && layer <= c->c.layer_hi;
+    if (nm == "features") { src = c->feat; have = (size_t)c->saved_n * c->E * 4; }
+    else if (nm == "dh") { src = c->dh; have = M * D * 4; }
+    else if (nm == "dqkv") { src = c->dqkv; have = M * c->ldwt * 2; }
+    else if (!tr) return fail(TTL_EINVAL, "%s: layer %d is not a trained (saved) layer", name, layer);
+    else {
+        Layer& l = c->layers[layer];
+        if (nm == "h_in") { src = l.h_in; have = M * D * 4; }
+        else if (nm == "h_mid") { src = l.h_mid; have = M * D * 4; }
+        else if (nm == "h_out") { src = c->h_out[layer - c->c.layer_lo]; have = M * D * 4; }
+        else if (nm == "qkv") { src = l.qkv; have = M * 3 * D * 2; }
+        else if (nm == "attn_out") { src = l.attn; have = M * D * 2; }
+        else if (nm == "x1") { src = l.x1ext; have = M * c->ldx * 2; }
+        else if (nm == "u") { src = l.u; have = M * F * 2; }
+        else if (nm == "lse") { src = l.lse; have = (size_t)c->saved_n * c->H * c->T * 4; }
+        else return fail(TTL_EINVAL, "unknown buffer %s", name);
+    }
+    if (bytes > have) return fail(TTL_EINVAL, "%s holds %zu bytes, %zu requested", name, have, bytes);
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ttl_profile_enable(ttl_ctx* c, int on) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    c->prof = on != 0;
+    return 0;
+}
+
+int ttl_profile_read(ttl_ctx* c, double ms[TTL_NCLASS], long long launches[TTL_NCLASS], double* gemm_flops) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& pe : c->prof_events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pe.second.first, pe.second.second) == hipSuccess) {
+            c->prof_ms[pe.first] += t;
+            c->prof_n[pe.first] += 1;
+        }
+        hipEventDestroy(pe.second.first);
+        hipEventDestroy(pe.second.second);
+    }
+    c->prof_events.clear();
+    for (int i = 0; i < TTL_NCLASS; ++i) {
+        if (ms) ms[i] = c->prof_ms[i];
+        if (launches) launches[i] = c->prof_n[i];
+        c->prof_ms[i] = 0; c->prof_n[i] = 0;
+    }
+    if (gemm_flops) *gemm_flops = c->gemm_flops;
+    c->gemm_flops = 0;
+    return 0;
+}
+
+}  // extern "C"

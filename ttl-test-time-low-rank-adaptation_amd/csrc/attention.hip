@@ -1,0 +1,367 @@
+// Fused non-causal attention for head dim 64 (CLIP ViT-B/16: T=197, ViT-L/14: T=257).
+//   forward : o = softmax(q k^T / 8) v, row logsumexp saved            (HF modeling_clip.py:259-277)
+//   backward: dq, dk, dv with P recomputed from the saved logsumexp     (autograd of the same)
+//
+// One workgroup (4 waves) per (view, head); the whole K/V (or Q/dO) of the head lives in LDS.
+// MFMA 32x32x16 bf16 everywhere.  Orientation is chosen so that NO accumulator ever crosses
+// lanes or LDS (guide §3 "accumulator tile as the next MFMA's operand"):
+//   forward / dQ pass : S^T = K Q^T (query on the lane) -> softmax is lane-local ->
+//                       O^T = V^T P^T,  dQ^T = K^T dS^T  take P^T / dS^T straight from registers;
+//                       V^T / K^T fragments come from ds_read_b64_tr_b16 on the row-major tile.
+//   dK/dV pass        : S = Q K^T (key on the lane) -> dV^T = dO^T P, dK^T = Q^T dS likewise.
+// LDS tiles are [rows][64] bf16 (128 B rows) filled by global_load_lds_dwordx4; 16-B chunk c of
+// row r sits at slot c ^ f(r), f(r) = ((r>>1)&1)<<2 | ((r>>2)&3): conflict-free for the
+// ds_read_b128 row reads AND for the transposed 4x16 block reads.
+#include "kernels.hpp"
+
+namespace {
+
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// byte offset of element (row, col) in a swizzled [rows][64] bf16 tile
+__device__ __forceinline__ int tile_off(int row, int col) {
+    return row * 128 + ((((col >> 3) ^ swz(row)) << 4) | ((col & 7) << 1));
+}
+
+// DMA rows [0,TP) of a [T][64] bf16 matrix (row stride ld elements) into a swizzled LDS tile;
+// rows >= T replicate row T-1 (finite data; their results are masked).
+template <int NKT>
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* g, int ld, int T, int tid, int wave) {
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {  // 32 rows x 8 chunks = 256 chunks per pass
+        int q = i * 256 + tid, r = q >> 3, p = q & 7;
+        int c = p ^ swz(r);
+        const bf16_t* src = g + (size_t)min(r, T - 1) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+}
+
+// A-operand fragment of X^T for k-step (rows kb..kb+15 of the row-major tile X, columns
+// cb..cb+31), in the k order of an accumulator-derived B operand:
+//   element j of lane half h  <->  row kb + 8*(j>>2) + 4*h + (j&3),  column cb + (lane&31)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int lane) {
+    const int h = lane >> 5, grp = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int col = cb + 16 * grp + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tile_off(kb + 4 * h + q, col)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tile_off(kb + 8 + 4 * h + q, col)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// row-read fragment: rows rb + (lane&31), 16-B chunk 2*ks + (lane>>5)
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int ks, int lane) {
+    const int r = rb + (lane & 31), c = 2 * ks + (lane >> 5);
+    return *(const bf16x8*)(tile + r * 128 + ((c ^ swz(r)) << 4));
+}
+
+__device__ __forceinline__ bf16x8 global_frag(const bf16_t* g, int ld, int row, int ks, int lane) {
+    return *(const bf16x8*)(g + (size_t)row * ld + 16 * ks + 8 * (lane >> 5));
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator -> bf16 operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+    u32x4 v = {pack_bf16x2(a[8 * s], a[8 * s + 1]), pack_bf16x2(a[8 * s + 2], a[8 * s + 3]),
+               pack_bf16x2(a[8 * s + 4], a[8 * s + 5]), pack_bf16x2(a[8 * s + 6], a[8 * s + 7])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// store a [64 x 32] transposed accumulator pair (rows = head-dim, column = this lane's token)
+__device__ __forceinline__ void store_ot(bf16_t* dst_row, const f32x16 (&o)[2], float mul, int lane) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int dh = 32 * dt + 8 * g + 4 * (lane >> 5);
+            *(u32x2*)(dst_row + dh) = u32x2{pack_bf16x2(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul),
+                                            pack_bf16x2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
+        }
+}
+
+constexpr float SCALE = 0.125f;  // head_dim^-0.5, head_dim = 64
+
+// ------------------------------------------------------------------------------ forward
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ out,
+                                                       int ldo, float* __restrict__ lse, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32;
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
+    stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
+    __syncthreads();
+
+    const int nqb = (T + 31) >> 5;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int qrow = min(qb * 32 + (lane & 31), T - 1);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = global_frag(qg, ld, qrow, ks, lane);
+        f32x16 st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 a = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (32 * kt + acc_row(r, lane) < T) ? a[r] * SCALE : -INFINITY;
+                a[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            st[kt] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __expf(st[kt][r] - mx);
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        f32x16 o[2] = {};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf = acc_frag(st[kt], s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, 32 * kt + 16 * s, 32 * dt, lane), pf,
+                                                                    o[dt], 0, 0, 0);
+            }
+        const int q = qb * 32 + (lane & 31);
+        if (q < T) {
+            store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / sum, lane);
+            if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = mx + __logf(sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward: dQ
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                          const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                          int ldo, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int ldd, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32;
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const bf16_t* og = out + (size_t)img * T * ldo + head * 64;
+    const bf16_t* dog = dout + (size_t)img * T * ldo + head * 64;
+    stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
+    stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
+    __syncthreads();
+
+    const int nqb = (T + 31) >> 5;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int q = qb * 32 + (lane & 31);
+        const int qrow = min(q, T - 1);
+        bf16x8 qf[4], dof[4];
+        float delta = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = global_frag(qg, ld, qrow, ks, lane);
+            dof[ks] = global_frag(dog, ldo, qrow, ks, lane);
+            bf16x8 of = global_frag(og, ldo, qrow, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        const float l = lse[((size_t)img * H + head) * T + qrow];
+        f32x16 dq[2] = {};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 s = {}, dp = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 32 * kt, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = (32 * kt + acc_row(r, lane) < T) ? __expf(s[r] * SCALE - l) : 0.f;
+                s[r] = p * (dp[r] - delta);  // dS^T
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                bf16x8 dsf = acc_frag(s, sb);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, 32 * kt + 16 * sb, 32 * dt, lane), dsf,
+                                                                     dq[dt], 0, 0, 0);
+            }
+        }
+        if (q < T) store_ot(dqkv + (size_t)(img * T + q) * ldd + head * 64, dq, SCALE, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------ backward: dK, dV
+template <int NKT, bool NEED_DK>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                           const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, int ldo,
+                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                           int ldd, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32;
+    char* sQ = smem;
+    char* sDO = smem + TP * 128;
+    float* sLse = (float*)(smem + 2 * TP * 128);
+    float* sDelta = sLse + TP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const bf16_t* og = out + (size_t)img * T * ldo + head * 64;
+    const bf16_t* dog = dout + (size_t)img * T * ldo + head * 64;
+    stage_tile<NKT>(sQ, qg, ld, T, tid, wave);
+    stage_tile<NKT>(sDO, dog, ldo, T, tid, wave);
+    for (int t = tid; t < TP; t += 256) {
+        int row = min(t, T - 1);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bf16x8 a = *(const bf16x8*)(dog + (size_t)row * ldo + 8 * c);
+            bf16x8 b = *(const bf16x8*)(og + (size_t)row * ldo + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)b[j];
+        }
+        sDelta[t] = d;
+        sLse[t] = lse[((size_t)img * H + head) * T + row];
+    }
+    __syncthreads();
+
+    const int nkb = (T + 31) >> 5;
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int key = kb * 32 + (lane & 31);
+        const int krow = min(key, T - 1);
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = global_frag(qg + D, ld, krow, ks, lane);
+            vf[ks] = global_frag(qg + 2 * D, ld, krow, ks, lane);
+        }
+        f32x16 dv[2] = {}, dk[2] = {};
+#pragma unroll 1
+        for (int qt = 0; qt < NKT; ++qt) {
+            f32x16 s = {}, dp = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int qi = 32 * qt + acc_row(r, lane);
+                float p = (qi < T) ? __expf(s[r] * SCALE - sLse[qi]) : 0.f;
+                s[r] = p;
+                ds[r] = p * (dp[r] - sDelta[qi]);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                bf16x8 pf = acc_frag(s, sb);
+                bf16x8 dsf = acc_frag(ds, sb);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDO, 32 * qt + 16 * sb, 32 * dt, lane), pf,
+                                                                     dv[dt], 0, 0, 0);
+                    if (NEED_DK)
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, 32 * qt + 16 * sb, 32 * dt, lane),
+                                                                         dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (key < T) {
+            bf16_t* base = dqkv + (size_t)(img * T + key) * ldd + head * 64;
+            store_ot(base + 2 * D, dv, 1.0f, lane);
+            if (NEED_DK) store_ot(base + D, dk, SCALE, lane);
+        }
+    }
+}
+
+template <typename K>
+hipError_t set_smem(K kernel, int bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int NKT>
+hipError_t fwd_t(const bf16_t* qkv, int ld, bf16_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+    constexpr int SMEM = 2 * NKT * 32 * 128;
+    static bool done = false;
+    if (!done) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<NKT>), dim3(n * H), dim3(256), SMEM, s, qkv, ld, out, ldo, lse, T, H);
+    return hipGetLastError();
+}
+
+template <int NKT>
+hipError_t bwd_t(const bf16_t* qkv, int ld, const bf16_t* out, const bf16_t* dout, int ldo, const float* lse,
+                 bf16_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s) {
+    constexpr int SMEM_A = 2 * NKT * 32 * 128;
+    constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT>, SMEM_A);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true>, SMEM_B);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false>, SMEM_B);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT>), dim3(n * H), dim3(256), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
+                       ldd, T, H);
+    if (need_dk)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true>), dim3(n * H), dim3(256), SMEM_B, s, qkv, ld, out, dout, ldo,
+                           lse, dqkv, ldd, T, H);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false>), dim3(n * H), dim3(256), SMEM_B, s, qkv, ld, out, dout, ldo,
+                           lse, dqkv, ldd, T, H);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int ld_out, float* lse, int n, int T, int H,
+                                hipStream_t s) {
+    int nkt = (T + 31) / 32;
+    if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 7) return fwd_t<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 9) return fwd_t<9>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out, const bf16_t* dout, int ld_o,
+                                const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+                                hipStream_t s) {
+    int nkt = (T + 31) / 32;
+    if (nkt <= 1) return bwd_t<1>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    if (nkt <= 2) return bwd_t<2>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    if (nkt <= 4) return bwd_t<4>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    if (nkt <= 7) return bwd_t<7>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    if (nkt <= 9) return bwd_t<9>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,225 @@
+// HBM-bound helpers around the GEMMs: casts, im2col of the N x 3 x S x S view batch, CLS rows,
+// LayerNorm forward/backward (wave per row, fp32 statistics).
+// Reference ops replaced: nn.LayerNorm (HF modeling_clip.py:605,358-360,607) and its autograd;
+// Conv2d input unfolding (:202-218).
+#include "kernels.hpp"
+
+namespace {
+
+__global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) {
+        float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
+        *(u32x4*)(dst + i) = u32x4{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+    }
+    // tail (n % 8) handled by the first thread
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t j = n & ~(size_t)7; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+}
+
+__global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst, int ld) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)rows * cols;
+    if (i >= n) return;
+    int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    dst[(size_t)r * ld + c] = f32_to_bf16(src[i]);
+}
+
+// 32x32 LDS-tiled transpose + cast
+__global__ void transpose_kernel(const float* __restrict__ src, int R, int C, bf16_t* __restrict__ dst, int ld) {
+    __shared__ float tile[32][33];
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;  // dst[c][r]
+        if (c < C && r < R) dst[(size_t)c * ld + r] = f32_to_bf16(tile[tx][j]);
+    }
+}
+
+// One thread converts 8 consecutive pixels of one image row: 32 B coalesced reads, 16 B writes
+// landing in the patch-major im2col matrix the patch GEMM consumes.
+__global__ void im2col_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int n, int S, int P, int Kp) {
+    const int G = S / P;
+    const int W8 = S / 8;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * 3 * S * W8;
+    if (t >= total) return;
+    int xs = (int)(t % W8) * 8;
+    size_t rest = t / W8;
+    int y = (int)(rest % S); rest /= S;
+    int c = (int)(rest % 3);
+    int img = (int)(rest / 3);
+    const float* src = x + (((size_t)img * 3 + c) * S + y) * S + xs;
+    float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int gy = y / P, py = y - gy * P;
+    if (P % 8 == 0) {
+        int gx = xs / P, px = xs - gx * P;
+        bf16_t* d = out + ((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px;
+        *(u32x4*)d = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    } else {  // P = 14 (ViT-L/14): 8-pixel groups straddle patches
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int xx = xs + e, gx = xx / P, px = xx - gx * P;
+            out[((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px] = f32_to_bf16(v[e]);
+        }
+    }
+}
+
+__global__ void cls_rows_kernel(float* __restrict__ h, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int n, int T, int D) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    int img = i / D, d = i - img * D;
+    h[(size_t)img * T * D + d] = cls[d] + pos[d];
+}
+
+// ---- LayerNorm: one wave per row, D <= 1024, D % 4 == 0.  Lane l owns float4 chunks l, l+64, ...
+constexpr int LN_MAXC = 4;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long row_stride,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y32, bf16_t* __restrict__ y16, int ld16,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const int nch = D >> 2;
+    const float* xr = x + (size_t)row * row_stride;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            v[i] = *(const float4*)(xr + 4 * c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+            float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
+            float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
+            if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
+            if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+        }
+    }
+}
+
+// dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * gamma,  xh = (x - mean) * rstd
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     float* __restrict__ o32, bf16_t* __restrict__ o16, int rows, int D) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const int nch = D >> 2;
+    const float mu = mean[row], rs = rstd[row];
+    float4 dxh[LN_MAXC], xh[LN_MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            float4 d = *(const float4*)(dy + (size_t)row * D + 4 * c);
+            float4 xv = *(const float4*)(x + (size_t)row * D + 4 * c);
+            float4 g = *(const float4*)(gamma + 4 * c);
+            dxh[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
+            s2 += (dxh[i].x * xh[i].x + dxh[i].y * xh[i].y) + (dxh[i].z * xh[i].z + dxh[i].w * xh[i].w);
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            float4 r = dres ? *(const float4*)(dres + (size_t)row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
+            float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
+            if (o32) *(float4*)(o32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
+            if (o16) *(u32x2*)(o16 + (size_t)row * D + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_cast_rows_f32_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
+    size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_f32_bf16(const float* src, int R, int C, bf16_t* dst, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, R, C, dst, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col(const float* x, bf16_t* patches, int n, int S, int P, int Kp, hipStream_t s) {
+    if (S % 8) return hipErrorInvalidValue;
+    size_t total = (size_t)n * 3 * S * (S / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, patches, n, S, P, Kp);
+    return hipGetLastError();
+}
+
+hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, int T, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((n * D + 255) / 256), dim3(256), 0, s, h, cls, pos, n, T, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta, float* y_f32,
+                            bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
+                            hipStream_t s) {
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, y_f32, y_bf16,
+                       ld_bf16, mean, rstd, rows, D, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16, int rows,
+                                int D, hipStream_t s) {
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
+                       out_bf16, rows, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }

@@ -1,0 +1,349 @@
+// Logit head, entropy / confidence-selection loss (forward + analytic backward), AdamW, reset.
+// All fp32 — these decide the selection mask, which must be bit-exact w.r.t. the reference.
+//
+//   head  : CLS -> post_layernorm -> visual_projection -> f/||f|| -> exp(logit_scale) f̂ t̂^T
+//           (HF modeling_clip.py:646-651,751; clip/custom_clip.py:680-687) and its backward
+//   loss  : deyo.py:85-90,102-113,159-181 (weighted entropy) / ttl.py:50-61 (TPT avg-entropy)
+//   adamw : torch.optim.AdamW over the flat LoRA buffer (ttl.py:218, deyo.py:187)
+//   reset : LoRA_AB.reset + optimizer.load_state_dict (clip/custom_clip.py:202-215, ttl.py:344)
+#include "kernels.hpp"
+
+namespace {
+
+constexpr int HB = 256;  // threads per head block
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// one block per view
+__global__ __launch_bounds__(HB) void head_fwd_kernel(HeadArgs a) {
+    extern __shared__ float sm[];
+    float* sy = sm;            // [D]
+    float* sf = sm + a.D;      // [E]
+    __shared__ float red[HB / 64];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const float* x = a.h + (size_t)v * a.T * a.D;
+    float s = 0.f;
+    for (int d = tid; d < a.D; d += HB) s += x[d];
+    const float mu = block_sum(s, red) / a.D;
+    float q = 0.f;
+    for (int d = tid; d < a.D; d += HB) { float c = x[d] - mu; q += c * c; }
+    const float rs = rsqrtf(block_sum(q, red) / a.D + a.eps);
+    for (int d = tid; d < a.D; d += HB) {
+        float y = (x[d] - mu) * rs * a.ln_g[d] + a.ln_b[d];
+        sy[d] = y;
+        a.y[(size_t)v * a.D + d] = y;
+    }
+    if (tid == 0) { a.cls_mean[v] = mu; a.cls_rstd[v] = rs; }
+    __syncthreads();
+    float nn = 0.f;
+    for (int e = tid; e < a.E; e += HB) {
+        float acc = 0.f;
+        for (int d = 0; d < a.D; ++d) acc = fmaf(sy[d], a.WpT[(size_t)d * a.E + e], acc);
+        sf[e] = acc;
+        a.f[(size_t)v * a.E + e] = acc;
+        if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
+        nn += acc * acc;
+    }
+    const float inv = a.scale / sqrtf(block_sum(nn, red));
+    for (int k = tid; k < a.K; k += HB) {
+        float acc = 0.f;
+        for (int e = 0; e < a.E; ++e) acc = fmaf(sf[e], a.tfeatT[(size_t)e * a.K + k], acc);
+        a.logits[(size_t)v * a.K + k] = acc * inv;
+    }
+}
+
+__global__ __launch_bounds__(HB) void head_bwd_kernel(HeadArgs a, const float* __restrict__ dlogits,
+                                                      float* __restrict__ dh, bf16_t* __restrict__ dh16) {
+    extern __shared__ float sm[];
+    float* sdz = sm;                 // [K]
+    float* sdf = sm + a.K;           // [E]
+    float* sdy = sm + a.K + a.E;     // [D]
+    __shared__ float red[HB / 64];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < a.K; k += HB) sdz[k] = dlogits[(size_t)v * a.K + k];
+    __syncthreads();
+    const float* f = a.f + (size_t)v * a.E;
+    float nn = 0.f;
+    for (int e = tid; e < a.E; e += HB) nn += f[e] * f[e];
+    const float nrm = sqrtf(block_sum(nn, red));
+    float dot = 0.f;
+    for (int e = tid; e < a.E; e += HB) {
+        float acc = 0.f;
+        for (int k = 0; k < a.K; ++k) acc = fmaf(sdz[k], a.tfeat[(size_t)k * a.E + e], acc);
+        acc *= a.scale;               // d/df̂
+        sdf[e] = acc;
+        dot += acc * (f[e] / nrm);
+    }
+    dot = block_sum(dot, red);
+    for (int e = tid; e < a.E; e += HB) sdf[e] = (sdf[e] - (f[e] / nrm) * dot) / nrm;  // d/df
+    __syncthreads();
+    // dy = df · Wp ; then LayerNorm backward on the CLS row
+    const float* x = a.h + (size_t)v * a.T * a.D;
+    const float mu = a.cls_mean[v], rs = a.cls_rstd[v];
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = tid; d < a.D; d += HB) {
+        float acc = 0.f;
+        for (int e = 0; e < a.E; ++e) acc = fmaf(sdf[e], a.Wp[(size_t)e * a.D + d], acc);
+        float dxh = acc * a.ln_g[d];
+        float xh = (x[d] - mu) * rs;
+        sdy[d] = dxh;
+        s1 += dxh;
+        s2 += dxh * xh;
+    }
+    const float m1 = block_sum(s1, red) / a.D;
+    const float m2 = block_sum(s2, red) / a.D;
+    for (int d = tid; d < a.D; d += HB) {
+        float xh = (x[d] - mu) * rs;
+        float o = rs * (sdy[d] - m1 - xh * m2);
+        dh[(size_t)v * a.T * a.D + d] = o;
+        if (dh16) dh16[(size_t)v * a.T * a.D + d] = f32_to_bf16(o);
+    }
+}
+
+// ---- loss, pass 1: one block per view: row softmax statistics -> H_i, lse_i
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ z, int K, float* __restrict__ Hout,
+                                                        float* __restrict__ lse) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float* zr = z + (size_t)i * K;
+    float mx = -INFINITY;
+    for (int k = tid; k < K; k += 256) mx = fmaxf(mx, zr[k]);
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int k = tid; k < K; k += 256) se += expf(zr[k] - mx);
+    se = block_sum(se, red);
+    const float l = mx + logf(se);
+    float h = 0.f;
+    for (int k = tid; k < K; k += 256) { float lp = zr[k] - l; h -= expf(lp) * lp; }
+    h = block_sum(h, red);
+    if (tid == 0) { Hout[i] = h; lse[i] = l; }
+}
+
+// ---- loss, pass 2 (single block): selection (bit-exact integer result from fp32 compares),
+// coefficients, loss.  rank_i = #{j : H_j < H_i or (H_j == H_i and j < i)} == position in a
+// stable ascending argsort.
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ H, int N, int objective, int mode,
+                                                     int ktop, float thresh, float margin, float reweight,
+                                                     int reuse_idx, long long* __restrict__ idx, int* __restrict__ n_io,
+                                                     float* __restrict__ loss, float* __restrict__ coef /*[N]*/,
+                                                     int* __restrict__ nsel_dev) {
+    __shared__ float red[4];
+    __shared__ int sn;
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) sn = 0;
+    __syncthreads();
+    const bool topk = (objective == 1) || (mode == 1);
+    int n;
+    if (objective == 1 && reuse_idx) {
+        n = *n_io;
+        for (int i = tid; i < N; i += 256) coef[i] = 0.f;
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) coef[idx[j]] = 1.f;
+        __syncthreads();
+    } else if (topk) {
+        n = ktop;  // int(N * selection_p), evaluated on the host in double like Python does
+        for (int i = tid; i < N; i += 256) {
+            float hi = H[i];
+            int rank = 0;
+            for (int j = 0; j < N; ++j) { float hj = H[j]; rank += (hj < hi) || (hj == hi && j < i); }
+            bool sel = rank < n;
+            coef[i] = sel ? 1.f : 0.f;
+            if (sel && idx) idx[rank] = i;
+        }
+        __syncthreads();
+    } else {
+        // torch.where(H <= thresh): ascending index order
+        for (int base = 0; base < N; base += 256) {
+            int i = base + tid;
+            bool sel = (i < N) && (H[i] <= thresh);
+            unsigned long long bal = __ballot(sel);
+            if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(bal);
+            __syncthreads();
+            int off = sn;
+            for (int w = 0; w < (tid >> 6); ++w) off += wcnt[w];
+            int pos = off + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if (i < N) coef[i] = sel ? 1.f : 0.f;
+            if (sel && idx) idx[pos] = i;
+            __syncthreads();
+            if (tid == 0) sn += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        n = sn;
+    }
+    if (tid == 0) { if (n_io) *n_io = n; *nsel_dev = n; }
+    if (objective == 0) {
+        // coeff_i = reweight / exp(H_i - margin) ; loss = mean_{i in S}(H_i * coeff_i)
+        float part = 0.f;
+        for (int i = tid; i < N; i += 256) {
+            float c = 0.f;
+            if (coef[i] != 0.f) {
+                c = (reweight != 0.f) ? reweight * (1.0f / expf(H[i] - margin)) : 1.0f;
+                part += H[i] * c;
+                c /= (float)n;
+            }
+            coef[i] = c;  // c_i / n, 0 for unselected
+        }
+        part = block_sum(part, red);
+        if (tid == 0 && loss) *loss = (n > 0) ? part / (float)n : 0.f;
+    }
+}
+
+// ---- loss, pass 3 (DeYO): dz_ik = -(c_i/n) p_ik (log p_ik + H_i)
+__global__ __launch_bounds__(256) void deyo_grad_kernel(const float* __restrict__ z, int K, const float* __restrict__ H,
+                                                        const float* __restrict__ lse, const float* __restrict__ coef,
+                                                        float* __restrict__ dz) {
+    const int i = blockIdx.x;
+    const float c = coef[i], h = H[i], l = lse[i];
+    const float* zr = z + (size_t)i * K;
+    float* dr = dz + (size_t)i * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float lp = zr[k] - l;
+        dr[k] = (c != 0.f) ? -c * expf(lp) * (lp + h) : 0.f;
+    }
+}
+
+// ---- TPT: avg_k = logsumexp_{i in S}(logp_ik) - log n ; loss = -sum_k avg_k e^{avg_k}
+// pass A (grid over class chunks): column statistics into scratch: cmax[k], csum[k]
+__global__ __launch_bounds__(256) void tpt_col_kernel(const float* __restrict__ z, int N, int K,
+                                                      const float* __restrict__ lse, const float* __restrict__ sel,
+                                                      const int* __restrict__ nsel, float* __restrict__ avg,
+                                                      float* __restrict__ gk) {
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    int n = *nsel;
+    if (n == 0) { avg[k] = 0.f; gk[k] = 0.f; gk[K + k] = 0.f; return; }
+    float mx = -INFINITY;
+    for (int i = 0; i < N; ++i) if (sel[i] != 0.f) mx = fmaxf(mx, z[(size_t)i * K + k] - lse[i]);
+    float se = 0.f;
+    for (int i = 0; i < N; ++i) if (sel[i] != 0.f) se += expf(z[(size_t)i * K + k] - lse[i] - mx);
+    float lsek = mx + logf(se);                // logsumexp over selected views
+    float a = lsek - logf((float)n);
+    a = fmaxf(a, -3.4028234663852886e38f);     // clamp(min=finfo.min), ttl.py:59-60
+    avg[k] = lsek;                             // keep the un-shifted lse for the weights
+    gk[k] = -(1.0f + a) * expf(a);             // dL/davg_k
+    // loss contribution reduced by the row kernel (needs a grid-wide sum): store -a e^a in place
+    gk[K + k] = -a * expf(a);
+}
+// pass B: one block per view: dz_ij = g_j w_ij - p_ij sum_k g_k w_ik, w_ik = exp(logp_ik - lse_k)
+__global__ __launch_bounds__(256) void tpt_grad_kernel(const float* __restrict__ z, int N, int K,
+                                                       const float* __restrict__ lse, const float* __restrict__ sel,
+                                                       const float* __restrict__ avg, const float* __restrict__ gk,
+                                                       float* __restrict__ dz, float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float* zr = z + (size_t)i * K;
+    float* dr = dz + (size_t)i * K;
+    if (i == 0 && loss) {
+        float part = 0.f;
+        for (int k = tid; k < K; k += 256) part += gk[K + k];
+        part = block_sum(part, red);
+        if (tid == 0) *loss = part;
+    }
+    if (sel[i] == 0.f) {
+        for (int k = tid; k < K; k += 256) dr[k] = 0.f;
+        return;
+    }
+    const float l = lse[i];
+    float sgw = 0.f;
+    for (int k = tid; k < K; k += 256) sgw += gk[k] * expf(zr[k] - l - avg[k]);
+    sgw = block_sum(sgw, red);
+    for (int k = tid; k < K; k += 256) {
+        float lp = zr[k] - l;
+        dr[k] = gk[k] * expf(lp - avg[k]) - expf(lp) * sgw;
+    }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, const int* __restrict__ nsel) {
+    if (nsel && *nsel == 0) return;  // deyo.py:183: no step when nothing was selected
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (!isfinite(gi)) return;       // GradScaler semantics: never step on inf/nan
+    float pi = p[i] * (1.0f - lr * wd);
+    float mi = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ void reset_kernel(float* __restrict__ p, const float* __restrict__ snap, float* __restrict__ m,
+                             float* __restrict__ v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    p[i] = snap[i];
+    if (m) m[i] = 0.f;
+    if (v) v[i] = 0.f;
+}
+
+}  // namespace
+
+hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
+    size_t sm = (size_t)(a.D + a.E) * sizeof(float);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(n), dim3(HB), sm, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, bf16_t* dh16, int n, hipStream_t s) {
+    size_t sm = (size_t)(a.K + a.E + a.D) * sizeof(float);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(n), dim3(HB), sm, s, a, dlogits, dh, dh16);
+    return hipGetLastError();
+}
+
+// scratch layout (floats): [0,N) lse | [N,2N) coef | [2N,2N+1) nsel(int) | [2N+4, 2N+4+N) H (if H_out null)
+//                          | then avg[K] | gk[2K]
+hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
+                               float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io, int* n_io,
+                               float* loss_out, float* dlogits, float* scratch, hipStream_t s) {
+    float* lse = scratch;
+    float* coef = scratch + N;
+    int* nsel = (int*)(scratch + 2 * N);
+    float* H = H_out ? H_out : scratch + 2 * N + 4;
+    float* avg = scratch + 3 * N + 4;
+    float* gk = avg + K;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(N), dim3(256), 0, s, logits, K, H, lse);
+    const int ktop = (int)((double)N * rho);  // Python: int(batch_entropy.size()[0] * top), ttl.py:52 / deyo.py:105
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, s, H, N, objective, mode, ktop, thresh, margin, reweight,
+                       reuse_idx, idx_io, n_io, loss_out, coef, nsel);
+    if (objective == 0) {
+        hipLaunchKernelGGL(deyo_grad_kernel, dim3(N), dim3(256), 0, s, logits, K, H, lse, coef, dlogits);
+    } else {
+        hipLaunchKernelGGL(tpt_col_kernel, dim3((K + 255) / 256), dim3(256), 0, s, logits, N, K, lse, coef, nsel, avg, gk);
+        hipLaunchKernelGGL(tpt_grad_kernel, dim3(N), dim3(256), 0, s, logits, N, K, lse, coef, avg, gk, dlogits, loss_out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                        float wd, int step, const int* n_selected, hipStream_t s) {
+    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                       wd, (float)bc1, (float)sqrt(bc2), n_selected);
+    return hipGetLastError();
+}
+
+hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, snap, m, v, n);
+    return hipGetLastError();
+}

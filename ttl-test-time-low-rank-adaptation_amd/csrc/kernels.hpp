@@ -1,0 +1,104 @@
+// Host-side launchers of the HIP kernels (one translation unit per kernel family).
+// All take a hipStream_t and enqueue only; none synchronises.
+#pragma once
+#include "common.hpp"
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[M,N] (+)= A[M,K] * B[N,K]^T with bf16 operands (row-major, K contiguous), fp32 accumulate
+// on v_mfma_f32_16x16x32_bf16.  Requirements: K % 64 == 0, N % 128 == 0, lda/ldb % 8 == 0.
+enum GemmEpi {
+    EPI_F32 = 0,       // C fp32 = acc (+ bias)
+    EPI_BF16 = 1,      // C bf16 = acc (+ bias)
+    EPI_RESID_F32 = 2, // C fp32 = resid + acc + bias
+    EPI_GELU = 3,      // C bf16 = quick_gelu(acc + bias); C2 bf16 = acc + bias (if C2)
+    EPI_PATCH = 4,     // C fp32 [(m/G2)*T + 1 + m%G2][n] = acc + pos[1 + m%G2][n]
+    EPI_GELU_BWD = 5,  // C bf16 = acc * quick_gelu'(aux[m][n])
+};
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* B; int ldb;
+    int M, N, K;
+    void* C; int ldc;
+    const float* bias;            // [N] or null
+    const float* resid; int ldr;  // EPI_RESID_F32
+    bf16_t* C2; int ldc2;         // EPI_GELU second output (pre-activation), may be null
+    const bf16_t* aux; int ldaux; // EPI_GELU_BWD: saved pre-activation u
+    const float* pos; int G2; int T; // EPI_PATCH
+};
+hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise (elementwise.hip)
+hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+// dst[r][c] = bf16(src[c][r])  (src [rows_src, cols_src] fp32 -> dst [cols_src, ld_dst] bf16)
+hipError_t launch_transpose_f32_bf16(const float* src, int rows_src, int cols_src, bf16_t* dst, int ld_dst,
+                                     hipStream_t s);
+// dst rows of ld_dst elements: bf16(src[r][c]) for c < cols, untouched beyond
+hipError_t launch_cast_rows_f32_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld_dst,
+                                     hipStream_t s);
+// patches[(n*G+gy)*G+gx][c*P*P+py*P+px] = bf16(x[n][c][gy*P+py][gx*P+px]); zero pad to Kp
+hipError_t launch_im2col(const float* x, bf16_t* patches, int n, int S, int P, int Kp, hipStream_t s);
+// h[n*T + 0][:] = cls + pos[0]
+hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, int T, int D, hipStream_t s);
+// LayerNorm over rows of fp32 x [rows, D].  y_f32 (ld D) and/or y_bf16 (ld ld_bf16) outputs;
+// mean/rstd optional saves.  row_stride: distance (elements) between consecutive input rows
+// (T*D to pick CLS rows).
+hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta,
+                            float* y_f32, bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
+                            int D, float eps, hipStream_t s);
+// dx = LN-backward(dy; x, mean, rstd, gamma); out_f32 = dres + dx; out_bf16 = bf16(out_f32)
+hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16,
+                                int rows, int D, hipStream_t s);
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int ld_out, float* lse, int n, int T,
+                                int H, hipStream_t s);
+hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out, const bf16_t* dout, int ld_o,
+                                const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+                                hipStream_t s);
+
+// ---------------------------------------------------------------- head / loss / optimizer (head_loss.hip)
+struct HeadArgs {
+    const float* h; int T; int D; int E; int K;   // h: fp32 residual stream [n*T, D]
+    const float* ln_g; const float* ln_b; float eps;
+    const float* WpT;      // [D][E] fp32 (visual_projection transposed)
+    const float* Wp;       // [E][D] fp32
+    const float* tfeat;    // [K][E]
+    const float* tfeatT;   // [E][K]
+    float scale;           // exp(logit_scale)
+    float* cls_mean; float* cls_rstd; float* y; float* f; // saves [n],[n],[n,D],[n,E]
+    float* logits;         // [n,K]
+    float* feats_out;      // optional [n,E]
+};
+hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s);
+// dlogits [n,K] -> dh rows n*T (CLS) fp32 + bf16 copy; other rows are NOT touched
+hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, bf16_t* dh_bf16, int n, hipStream_t s);
+
+hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
+                               float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io,
+                               int* n_io, float* loss_out, float* dlogits, float* scratch /*>= 4*N + K floats*/,
+                               hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                        float eps, float wd, int step, const int* n_selected, hipStream_t s);
+hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- LoRA (lora.hip)
+// Refresh the bf16 images derived from the fp32 LoRA params of ONE layer:
+//   wqkv_ext [3D][ldw]: cols D..D+r of rows 0..D = B_q ; cols D+r..D+2r of rows 2D..3D = B_v
+//   wqkvT_ext [D][ldwt]: cols 3D..3D+r = A_q^T ; cols 3D+r..3D+2r = A_v^T
+//   a_cat [2r][D] = [A_q; A_v] ;  bT_cat [2r][D] = [B_q^T; B_v^T]
+hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av, const float* Bv, int D, int r,
+                               bf16_t* wqkv_ext, int ldw, bf16_t* wqkvT_ext, int ldwt, bf16_t* a_cat,
+                               bf16_t* bT_cat, hipStream_t s);
+// out[m][c] = bf16(scale * sum_k X[m][xoff(c) + k] * Wcat[c][k]),  c in [0,2r), k in [0,D)
+//   xoff(c) = (c < r) ? xoff_q : xoff_v   (lora_down: both 0; dU: dq at 0, dv at 2D)
+hipError_t launch_lora_skinny(const bf16_t* X, int ldx, int xoff_q, int xoff_v, const bf16_t* Wcat, int D, int r,
+                              float scale, bf16_t* out, int ldo, int M, hipStream_t s);
+// LoRA weight gradients of one layer from saved activations:
+//   dB_q = dq^T Us_q, dB_v = dv^T Us_v, dA_q = dU_q^T x1, dA_v = dU_v^T x1      (Us = s*x1*A^T)
+// x1ext [M][ldx]: cols 0..D = x1, cols D..D+2r = Us ; dqkv [M][ldd]: dq | dk | dv | dU_q dU_v
+// partial: fp32 scratch [nchunk][4][r][D]; grads written to gAq [r,D], gBq [D,r], gAv, gBv
+hipError_t launch_lora_wgrad(const bf16_t* x1ext, int ldx, const bf16_t* dqkv, int ldd, int M, int D, int r,
+                             float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s);
+int lora_wgrad_chunks(int M);

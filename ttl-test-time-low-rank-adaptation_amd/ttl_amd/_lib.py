@@ -1,0 +1,112 @@
+"""ctypes binding of libttl_hip.so (C ABI declared in include/ttl_hip.h).
+
+There is no fallback: if the shared library is missing or does not export every symbol the
+header declares, importing the product path raises.  Build it with
+``make -C ttl-test-time-low-rank-adaptation_amd/csrc`` (or ``python __graft_entry__.py``).
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttl_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ttl_hip.h"))
+
+TTL_SEL_LE_THRESH = 0
+TTL_SEL_TOPK = 1
+TTL_NCLASS = 6
+PROFILE_CLASSES = ("gemm", "attention_fwd", "attention_bwd", "layernorm_elementwise", "lora", "head_loss_opt")
+
+
+class TtlError(RuntimeError):
+    pass
+
+
+class ttl_config(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("patch_size", C.c_int), ("width", C.c_int), ("heads", C.c_int),
+                ("mlp", C.c_int), ("layers", C.c_int), ("embed", C.c_int), ("rank", C.c_int),
+                ("lora_alpha", C.c_float), ("layer_lo", C.c_int), ("layer_hi", C.c_int), ("ln_eps", C.c_float),
+                ("max_views", C.c_int), ("max_classes", C.c_int)]
+
+
+class ttl_episode_args(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("n_views", C.c_int), ("n_updates", C.c_int), ("objective", C.c_int),
+                ("mode", C.c_int), ("rho", C.c_double), ("thresh", C.c_float), ("margin", C.c_float),
+                ("reweight", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("snapshot", C.c_void_p),
+                ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("logits0_out", C.c_void_p),
+                ("logits1_out", C.c_void_p)]
+
+
+_P, _I, _F, _D, _Z = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+# name -> (restype, argtypes); must cover every function declared in include/ttl_hip.h
+SIGNATURES = {
+    "ttl_last_error": (C.c_char_p, []),
+    "ttl_version": (C.c_char_p, []),
+    "ttl_workspace_bytes": (_Z, [C.POINTER(ttl_config)]),
+    "ttl_ctx_create": (_I, [C.POINTER(ttl_config), C.POINTER(_P)]),
+    "ttl_ctx_destroy": (None, [_P]),
+    "ttl_load_weight": (_I, [_P, C.c_char_p, _P, _Z]),
+    "ttl_weights_ready": (_I, [_P]),
+    "ttl_set_text_features": (_I, [_P, _P, _I, _F, _P]),
+    "ttl_bind_lora": (_I, [_P, _P, _P, _Z]),
+    "ttl_vit_forward": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "ttl_entropy_select_loss": (_I, [_P, _I, _I, _I, _D, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "ttl_tpt_select_loss": (_I, [_P, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P]),
+    "ttl_vit_backward_lora": (_I, [_P, _P, _I, _P]),
+    "ttl_adamw_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "ttl_lora_reset": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "ttl_episode": (_I, [_P, C.POINTER(ttl_episode_args), _P]),
+    "ttl_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ttl_layernorm_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "ttl_cast_f32_bf16": (_I, [_P, _P, _Z, _P]),
+    "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ttl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),
+    "ttl_profile_enable": (_I, [_P, _I]),
+    "ttl_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+}
+
+
+def header_symbols(path=HEADER_PATH):
+    """Function names declared in the public header (used by the CPU export test)."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ttl_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load(path=LIB_PATH):
+    """dlopen the library and attach signatures.  Raises TtlError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise TtlError(f"{path} not found: the HIP extension is not built "
+                       f"(run `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}`); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  — load torch's libamdhip64 first so both share one HIP runtime
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise TtlError(f"{path} does not export: {', '.join(missing)}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ttl_last_error()
+        raise TtlError(f"libttl_hip error {rc}: {msg.decode() if msg else '?'}")

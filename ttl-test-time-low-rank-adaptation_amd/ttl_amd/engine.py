@@ -1,0 +1,197 @@
+"""Thin torch-facing wrapper around one libttl_hip context.
+
+torch is plumbing here (device memory, streams); every computation on the hot path is a
+call into the C ABI (include/ttl_hip.h).  One engine = one GPU = one process.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import VitConfig
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TTLEngine:
+    """Owns the HIP context (frozen bf16 weights + activation arena) of one image tower."""
+
+    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.TtlError("TTLEngine needs a GPU device: the hot path has no CPU implementation "
+                                "(oracle/ is a test checker, not a fallback)")
+        self.max_views, self.max_classes = int(max_views), int(max_classes)
+        self.n_classes = 0
+        c = _lib.ttl_config(cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers,
+                            cfg.embed, cfg.rank, cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps,
+                            self.max_views, self.max_classes)
+        self._ccfg = c
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self.n_lora = (cfg.layer_hi - cfg.layer_lo + 1) * 4 * cfg.rank * cfg.width
+        self.grads = torch.zeros(self.n_lora, dtype=torch.float32, device=self.device)
+        self._params = None
+        self._keep = []
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ttl_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.ttl_workspace_bytes(C.byref(self._ccfg)))
+
+    # ------------------------------------------------------------------ setup
+    def load_weights(self, state: dict):
+        """state: HF vision-tower names -> fp32 numpy arrays or torch tensors (any device)."""
+        with torch.cuda.device(self.device):
+            for name, a in state.items():
+                if name == "logit_scale":
+                    continue
+                if isinstance(a, torch.Tensor):
+                    a = a.detach().to(torch.float32).contiguous()
+                    if a.is_cuda and a.device != self.device:
+                        a = a.to(self.device)
+                    ptr, cnt = C.c_void_p(a.data_ptr()), a.numel()
+                else:
+                    a = np.ascontiguousarray(a, dtype=np.float32)
+                    ptr, cnt = a.ctypes.data_as(C.c_void_p), a.size
+                _lib.check(self.lib.ttl_load_weight(self._h, name.encode(), ptr, cnt))
+            _lib.check(self.lib.ttl_weights_ready(self._h))
+
+    def set_text_features(self, tfeat: torch.Tensor, logit_scale_exp: float):
+        """tfeat: [K,E] unit-norm class embeddings (clip/custom_clip.py:651-663)."""
+        t = tfeat.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_set_text_features(self._h, _ptr(t), t.shape[0], float(logit_scale_exp), _stream()))
+        self.n_classes = int(t.shape[0])
+
+    def bind_lora(self, params_flat: torch.Tensor):
+        assert params_flat.numel() == self.n_lora and params_flat.dtype == torch.float32
+        self._params = params_flat
+        _lib.check(self.lib.ttl_bind_lora(self._h, _ptr(params_flat), _ptr(self.grads), self.n_lora))
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, x: torch.Tensor, save: bool = False, want_features: bool = False):
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        n = x.shape[0]
+        logits = torch.empty((n, self.n_classes), dtype=torch.float32, device=self.device)
+        feats = torch.empty((n, self.cfg.embed), dtype=torch.float32, device=self.device) if want_features else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_vit_forward(self._h, _ptr(x), n, 1 if save else 0, _ptr(logits), _ptr(feats), _stream()))
+        return (logits, feats) if want_features else logits
+
+    def backward(self, dlogits: torch.Tensor):
+        d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
+        return self.grads
+
+    def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0):
+        """-> dict(H [N], idx int64 [N] (first n valid), n int32 [1], loss [1], dlogits [N,K]); all device tensors."""
+        import math
+        z = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        N, K = z.shape
+        dev = self.device
+        out = dict(H=torch.empty(N, device=dev), idx=torch.zeros(N, dtype=torch.int64, device=dev),
+                   n=torch.zeros(1, dtype=torch.int32, device=dev), loss=torch.zeros(1, device=dev),
+                   dlogits=torch.empty_like(z))
+        th = math.log(1000.0) if thresh is None else thresh
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.ttl_entropy_select_loss(_ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
+                                                        float(reweight), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
+                                                        _ptr(out["loss"]), _ptr(out["dlogits"]), _stream()))
+        return out
+
+    def tpt_select_loss(self, logits, rho=0.1, idx=None, n=None):
+        z = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        N, K = z.shape
+        dev = self.device
+        reuse = idx is not None
+        out = dict(H=torch.empty(N, device=dev),
+                   idx=idx if reuse else torch.zeros(N, dtype=torch.int64, device=dev),
+                   n=n if reuse else torch.zeros(1, dtype=torch.int32, device=dev),
+                   loss=torch.zeros(1, device=dev), dlogits=torch.empty_like(z))
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.ttl_tpt_select_loss(_ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
+                                                    _ptr(out["idx"]), _ptr(out["n"]), _ptr(out["loss"]),
+                                                    _ptr(out["dlogits"]), _stream()))
+        return out
+
+    def adamw_step(self, params, grads, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                   n_selected=None):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
+                                               betas[1], eps, weight_decay, int(step), _ptr(n_selected), _stream()))
+
+    def lora_reset(self, params, snapshot, m=None, v=None):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_lora_reset(_ptr(params), _ptr(snapshot), _ptr(m), _ptr(v), params.numel(), _stream()))
+
+    def episode(self, x, snapshot, m, v, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH, rho=0.1,
+                thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                want_logits0=False):
+        """One whole test image (ttl.py:338-352) as a single enqueue; returns logits1 [1,K] (and logits0)."""
+        import math
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        n = x.shape[0]
+        l1 = torch.empty((1, self.n_classes), dtype=torch.float32, device=self.device)
+        l0 = torch.empty((n, self.n_classes), dtype=torch.float32, device=self.device) if want_logits0 else None
+        a = _lib.ttl_episode_args()
+        a.x, a.n_views, a.n_updates = x.data_ptr(), n, int(n_updates)
+        a.objective = 0 if objective == "deyo" else 1
+        a.mode, a.rho = int(mode), float(rho)
+        a.thresh = math.log(1000.0) if thresh is None else thresh
+        a.margin, a.reweight = float(margin), float(reweight)
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, betas[0], betas[1], eps, weight_decay
+        a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.logits0_out = l0.data_ptr() if want_logits0 else None
+        a.logits1_out = l1.data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
+        return (l1, l0) if want_logits0 else l1
+
+    # ------------------------------------------------------------------ debugging / measurement
+    def debug_copy(self, name, layer, shape, dtype=np.float32):
+        a = np.empty(shape, dtype=dtype)
+        _lib.check(self.lib.ttl_debug_copy(self._h, name.encode(), int(layer), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.ttl_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * _lib.TTL_NCLASS)()
+        cnt = (C.c_longlong * _lib.TTL_NCLASS)()
+        fl = C.c_double()
+        _lib.check(self.lib.ttl_profile_read(self._h, ms, cnt, C.byref(fl)))
+        return ({k: ms[i] for i, k in enumerate(_lib.PROFILE_CLASSES)},
+                {k: cnt[i] for i, k in enumerate(_lib.PROFILE_CLASSES)}, fl.value)
+
+
+def bf16_bits_to_f32(a: np.ndarray) -> np.ndarray:
+    """uint16 bf16 storage -> float32 (helper for tests reading debug buffers)."""
+    return (a.astype(np.uint32) << 16).view(np.float32)
