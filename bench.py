@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — test images/sec of TTL's per-sample hot path on MI355X.
+
+One "step" = one test image = reset -> 64-view CLIP ViT-B/16 forward -> entropy-weighted loss ->
+backward into the rank-16 LoRA adapters of layers 9-11 -> AdamW -> adapted 1-view inference
+(the loop body of the reference's ttl.py:338-352), on synthetic views already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Multi-GPU: images shard across ranks (weak scaling, no data-path
+collective); the only collectives are the timing barrier/max and the 3-int accuracy all-reduce.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def episode_flops(cfg, n_views, n_classes):
+    """Algorithmic FLOPs of one test image (SURVEY.md §8d / BASELINE.md §2)."""
+    D, F, T, H, L, E, r, P = cfg.width, cfg.mlp, cfg.tokens, cfg.heads, cfg.layers, cfg.embed, cfg.rank, cfg.patch_size
+
+    def fwd(n):
+        M = n * T
+        layer = 2 * M * (4 * D * D + 2 * D * F) + 4 * n * H * T * T * 64
+        lora = 8 * M * D * r
+        nt = cfg.layer_hi - cfg.layer_lo + 1
+        return 2 * n * (T - 1) * 3 * P * P * D + L * layer + nt * lora + 2 * n * (D * E + E * n_classes)
+
+    M = n_views * T
+    nt = cfg.layer_hi - cfg.layer_lo + 1
+    full = 2 * M * (4 * D * D + 2 * D * F) + 8 * n_views * H * T * T * 64 + 16 * M * D * r
+    first = 2 * M * (D * D + 2 * D * F) + 6 * n_views * H * T * T * 64 + 12 * M * D * r
+    bwd = (nt - 1) * full + first + 2 * n_views * (D * E + E * n_classes)
+    return fwd(n_views) + bwd + fwd(1)
+
+
+def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
+    """Oracle (numpy fp32 restatement, validated against the reference goldens) timed on this
+    host.  A 4-view probe sizes the sample so that it stays inside ~``budget_s`` of CPU work;
+    cost is linear in views, so the result is scaled to the full view count."""
+    from oracle import ttl_oracle as O
+    from ttl_amd import synth
+    W = synth.vision_weights(cfg, 0)
+    lora = synth.lora_init(cfg, 0)
+    tf = synth.text_features(n_classes, cfg.embed)
+    t0 = time.time()
+    O.episode(cfg, W, lora, synth.views(cfg, 4, 11), tf, prec="fp32")
+    probe = time.time() - t0
+    sample_views = full_views
+    while sample_views > 4 and probe * sample_views / 4 > budget_s:
+        sample_views //= 2
+    x = synth.views(cfg, sample_views, 11)
+    t0 = time.time()
+    O.episode(cfg, W, lora, x, tf, prec="fp32")
+    dt = time.time() - t0
+    return {"value": round(1.0 / (dt * full_views / sample_views), 5), "unit": "images/sec",
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 episode of oracle/ttl_oracle.py (numpy fp32, BLAS threads = all cores) on {sample_views} of "
+                      f"{full_views} views, K={n_classes}: {dt:.1f} s, scaled by {sample_views}/{full_views} "
+                      f"(cost is linear in views; text features cached like the GPU path)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--arch", default="ViT-B/16")
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=200)       # ImageNet-A label-set size (configs[1])
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--updates", type=int, default=1)
+    ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ttl_amd import synth, _lib
+    from ttl_amd.config import get_config
+    from ttl_amd.engine import TTLEngine
+
+    cfg = get_config(a.arch).replace(rank=a.rank)
+    eng = TTLEngine(cfg, a.views, a.classes, dev)
+    eng.load_weights(synth.vision_weights(cfg, 0))
+    eng.set_text_features(torch.from_numpy(synth.text_features(a.classes, cfg.embed)), 100.0)
+    lora = synth.lora_init(cfg, 0)
+    names = [f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight"
+             for i in range(cfg.layer_lo, cfg.layer_hi + 1) for pj in ("q_proj", "v_proj") for ab in ("A", "B")]
+    flat = torch.cat([torch.from_numpy(lora[k]).reshape(-1) for k in names]).to(dev).contiguous()
+    eng.bind_lora(flat)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    # synthetic inputs of the workload's shape, already resident in HBM (data: synthetic)
+    pool = [torch.from_numpy(synth.views(cfg, a.views, 1000 + rank * a.pool + j)).to(dev) for j in range(a.pool)]
+    labels = torch.arange(a.pool, device=dev) % a.classes
+    hits = torch.zeros(3, dtype=torch.int64, device=dev)
+
+    def step(i):
+        l1 = eng.episode(pool[i % a.pool], snap, m, v, n_updates=a.updates)
+        hits[0] += (l1.argmax(1) == labels[i % a.pool]).sum()
+        hits[2] += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM)      # C1: accuracy accumulator
+    T = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        eng.profile_enable(True)
+        nprof = 5
+        for i in range(nprof):
+            step(i)
+        ms, cnt, gflops = eng.profile_read()
+        eng.profile_enable(False)
+        ach = gflops / (ms["gemm"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_kernel<128,*> (all epilogues)",
+                "flops_per_launch": round(gflops / max(cnt["gemm"], 1)),
+                "avg_launch_us": round(1e3 * ms["gemm"] / max(cnt["gemm"], 1), 2),
+                "launches_per_image": cnt["gemm"] // nprof,
+                "class_ms_per_image": {k: round(val / nprof, 3) for k, val in ms.items()}}
+    if rank == 0:
+        value = world * a.steps / T
+        flops = episode_flops(cfg, a.views, a.classes) * a.updates  # (1-view inference counted once per update: <2%)
+        out = {
+            "metric": "test images/sec (64-view TTA, 1 step), CLIP ViT-B/16 r=16",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * T / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} r={cfg.rank}, {a.views} views, {a.updates} TTA step, K={a.classes} "
+                                   f"(ImageNet-A shape), layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
+                                   f"1-view inference; views pre-staged in HBM; {a.steps} images/rank",
+                       "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates,
+                       "parallelism": f"image-sharded x{world}"},
+            "tflop_per_image": round(flops / 1e12, 3),
+            "whole_path_tflops_per_gpu": round(flops * value / world / 1e12, 1),
+            "whole_path_frac_of_bf16_peak": round(flops * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "top1_self_consistency": {"hits": int(hits[0].item()), "count": int(hits[2].item())},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.classes)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""-m gpu: the drop-in surface.  A loop shaped like the reference's ttl.py:338-352 drives this
+build's ClipTestTimeTuning / test_time_tuning; a second loop uses the REFERENCE's formulation of
+the step (torch loss on the logits, loss.backward(), torch AdamW) on top of model(x) to prove the
+autograd hook, so the reference's own deyo.py/ttl.py bodies run on the HIP model unmodified."""
+import argparse
+import copy
+import math
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from helpers import load_case, episode_kwargs, max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_args(**over):
+    a = argparse.Namespace(lr=5e-3, selection_p=0.1, tta_steps=1, cocoop=False, lora_encoder="image", deyo_selection=True,
+                           deyo_margin=0.5, deyo_margin_e0=0.4, filter_ent=0, filter_plpd=0, reweight_ent=1, reweight_plpd=0)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def build(name):
+    from ttl_amd.custom_clip import ClipTestTimeTuning
+    g, cfg, W, x, lora0, tf = load_case(name)
+    model = ClipTestTimeTuning(0, [f"c{i}" for i in range(tf.shape[0])], None, arch=cfg.name,
+                               layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier", lora_encoder="image",
+                               rank=cfg.rank, max_views=x.shape[0], max_classes=tf.shape[0], weight_seed=0)
+    # fixture state: the reference's xavier draw for A and its text features
+    with torch.no_grad():
+        for i, layer in enumerate(model.image_encoder.vision_model.encoder.layers):
+            for pj in ("q_proj", "v_proj"):
+                key = f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_A.default.weight"
+                getattr(layer.self_attn, pj).lora_A.default.weight.copy_(torch.from_numpy(lora0[key]))
+        model.LoRA_AB.init_weights = []
+        for layer in model.image_encoder.vision_model.encoder.layers:
+            sa = layer.self_attn
+            model.LoRA_AB.init_weights.append(tuple(t.detach().clone() for t in (
+                sa.q_proj.lora_A.default.weight, sa.q_proj.lora_B.default.weight,
+                sa.v_proj.lora_A.default.weight, sa.v_proj.lora_B.default.weight)))
+    tft = torch.from_numpy(tf).cuda()
+    model.get_text_features = lambda: tft
+    model._text_dirty = True
+    # ttl.py:151-163 / :189-220
+    for n, p in model.named_parameters():
+        p.requires_grad_("image_encoder" in n and ("lora_A" in n or "lora_B" in n)
+                         and any(f"layers.{i}." in n for i in range(cfg.layer_lo, cfg.layer_hi + 1)))
+    groups = []
+    for i, layer in enumerate(model.image_encoder.vision_model.encoder.layers):
+        if cfg.layer_lo <= i <= cfg.layer_hi:
+            groups += [{"params": layer.self_attn.q_proj.lora_A.parameters()}, {"params": layer.self_attn.q_proj.lora_B.parameters()},
+                       {"params": layer.self_attn.v_proj.lora_A.parameters()}, {"params": layer.self_attn.v_proj.lora_B.parameters()}]
+    opt = torch.optim.AdamW(groups, lr=5e-3)
+    return g, cfg, model, opt, copy.deepcopy(opt.state_dict()), torch.from_numpy(x).cuda()
+
+
+def named_lora(model, cfg):
+    out = {}
+    for n, p in model.named_parameters():
+        if "lora" in n and any(f"layers.{i}." in n for i in range(cfg.layer_lo, cfg.layer_hi + 1)):
+            out[n.replace("image_encoder.", "")] = p.detach().cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_tpt"])
+def test_reference_shaped_loop(name):
+    from ttl_amd.ttl import test_time_tuning
+    g, cfg, model, opt, opt_state, x = build(name)
+    kw = episode_kwargs(g)
+    args = ref_args(filter_ent=1 if (kw["mode"] == "topk" and kw["objective"] == "deyo") else 0,
+                    deyo_selection=(kw["objective"] == "deyo"),
+                    tta_steps={1: 1, 4: 2, 2: 2}[kw["n_updates"]])
+    scaler = torch.amp.GradScaler("cuda", init_scale=1000)
+    model.eval()
+    outs = []
+    for rep in range(2):                      # two "images": the second must see a fully reset state
+        with torch.no_grad():
+            model.LoRA_reset()                                   # ttl.py:343
+        opt.load_state_dict(opt_state)                           # ttl.py:344
+        test_time_tuning(model, x, opt, scaler, args)            # ttl.py:347
+        with torch.no_grad():
+            out = model(x[:1])                                   # ttl.py:352
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]), "episodic reset is not complete"
+    assert max_rel(outs[0], g["logits1"]) < 3e-2
+    assert int(outs[0].argmax()) == int(g["top5"][0, 0])
+    lora1 = named_lora(model, cfg)
+    frac_bad = np.mean([float((np.abs(lora1[k] - g["lora1/" + k]) > 1e-3).mean()) for k in lora1])
+    assert frac_bad < 0.2, frac_bad
+    steps = int(opt.state[model.trainable_lora_parameters()[0]]["step"].item())
+    assert steps == kw["n_updates"]                              # tta_steps**2 on the DeYO branch (Q6)
+
+
+def test_fused_runner_equals_stepwise_surface():
+    from ttl_amd.driver import EpisodeRunner
+    from ttl_amd.ttl import test_time_tuning
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    args = ref_args()
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    test_time_tuning(model, x, opt, None, args)
+    with torch.no_grad():
+        a = model(x[:1]).clone()
+    b = EpisodeRunner(model, args)(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_reference_formulation_through_autograd():
+    """deyo.py:97-108,175-188 verbatim in torch on top of model(x): exercises the autograd hook."""
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    outputs = model(x)
+    assert outputs.requires_grad
+    entropys = -(outputs.softmax(1) * outputs.log_softmax(1)).sum(1)
+    ids = torch.where(entropys <= math.log(1000))
+    entropys = entropys[ids]
+    coeff = 1 * (1 / torch.exp(entropys.clone().detach() - 0.4))
+    loss = entropys.mul(coeff).mean(0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1000)
+    opt.zero_grad()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    lora1 = named_lora(model, cfg)
+    for k, v in lora1.items():
+        gref = g["grad/" + k]
+        p = dict(model.named_parameters())["image_encoder." + k]
+        if np.abs(gref).max() > 0:
+            assert max_rel(p.grad.cpu().numpy(), gref) < 4e-2, k          # grads were unscaled by the GradScaler
+    frac_bad = np.mean([float((np.abs(lora1[k] - g["lora1/" + k]) > 1e-3).mean()) for k in lora1])
+    assert frac_bad < 0.05, frac_bad
+    with torch.no_grad():
+        out = model(x[:1])
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 3e-2

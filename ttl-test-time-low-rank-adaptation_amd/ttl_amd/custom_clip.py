@@ -1,0 +1,407 @@
+"""Host-side mirror of the reference's LoRA-CLIP wrapper, for the image-LoRA path only.
+
+Same names, argument meaning and error behaviour as clip/custom_clip.py of the reference:
+``ClipTestTimeTuning`` (:570-703), ``LoRA_AB`` (:139-217), ``VisionEncoder`` (:62-71),
+``PromptEncoder`` (:73-82), ``get_coop`` (:706-723; exported as ``get_ttl`` too — the name
+BASELINE.json uses).  The module tree exposes exactly the parameter names the reference's
+driver filters on and reaches into (ttl.py:159-160, :193-201):
+
+    image_encoder.vision_model.encoder.layers.{i}.self_attn.{q_proj,v_proj}.lora_{A,B}.default.weight
+
+What differs by design (MI355X-native):
+  * the frozen image tower lives in a libttl_hip context as bf16 MFMA operand images, not as
+    nn.Parameters; ``model(x)`` runs the HIP kernels and is differentiable w.r.t. the LoRA
+    parameters through a torch.autograd.Function whose backward is ttl_vit_backward_lora,
+    so the reference's own deyo.py / ttl.py loops run on it unmodified;
+  * text features are computed once per ``reset_classnames`` and cached (they are constant when
+    lora_encoder == 'image'; the reference recomputes them in every forward — SURVEY Q12);
+  * adapters of layers outside ``layer_range`` have B == 0 forever in the reference (Q10) and are
+    therefore numerically absent here; their Parameters still exist for name-compatibility.
+The text tower stays PyTorch (transformers.CLIPModel), as BASELINE.json's north_star asks.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from . import synth
+from .config import get_config
+from .engine import TTLEngine
+
+CLIP_WEIGHTS_ENV = "TTL_CLIP_WEIGHTS"   # local HF checkpoint dir of openai/clip-vit-base-patch16 (optional)
+
+
+# ------------------------------------------------------------------------------- module tree
+class _LoRAProj(nn.Module):
+    """Stand-in for peft's LoRA Linear on q_proj / v_proj: only the adapter lives in torch."""
+
+    def __init__(self, dim, rank, alpha):
+        super().__init__()
+        self.lora_A = nn.ModuleDict({"default": nn.Linear(dim, rank, bias=False)})
+        self.lora_B = nn.ModuleDict({"default": nn.Linear(rank, dim, bias=False)})
+        self.scaling = {"default": alpha / rank}
+        nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))   # peft default
+        nn.init.zeros_(self.lora_B["default"].weight)
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, dim, rank, alpha):
+        super().__init__()
+        self.q_proj = _LoRAProj(dim, rank, alpha)
+        self.v_proj = _LoRAProj(dim, rank, alpha)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, dim, rank, alpha):
+        super().__init__()
+        self.self_attn = _SelfAttn(dim, rank, alpha)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(cfg.width, cfg.rank, cfg.lora_alpha) for _ in range(cfg.layers)])
+
+
+class _VisionModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.encoder = _Encoder(cfg)
+
+
+class _VitLogitsFn(torch.autograd.Function):
+    """logits = HIP forward; backward = HIP LoRA backward (dlogits -> 4 grads per trained layer)."""
+
+    @staticmethod
+    def forward(ctx, owner, save, x, *params):
+        ctx.owner = owner
+        ctx.shapes = [p.shape for p in params]
+        return owner._engine_forward(x, save=save)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        flat = ctx.owner.engine.backward(dlogits.contiguous())
+        outs, off = [], 0
+        for s in ctx.shapes:
+            n = int(np.prod(s))
+            outs.append(flat[off:off + n].view(s).clone())
+            off += n
+        return (None, None, None, *outs)
+
+
+class VisionEncoder(nn.Module):
+    """clip/custom_clip.py:62-71.  ``forward(image)`` returns image features [N,E]."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.vision_model = _VisionModel(cfg)
+        self.dtype = torch.float32
+        self._owner = None
+
+    def forward(self, image):
+        return self._owner.image_features_of(image)
+
+
+class PromptEncoder(nn.Module):
+    """clip/custom_clip.py:73-82: tokenized prompts -> text features, on PyTorch (HF CLIP text tower)."""
+
+    def __init__(self, clip_model):
+        super().__init__()
+        self.text_model = clip_model.text_model
+        self.text_projection = clip_model.text_projection
+        self.dtype = torch.float32
+
+    def forward(self, prompts):
+        out = self.text_model(input_ids=prompts)
+        pooled = out.pooler_output if hasattr(out, "pooler_output") else out[1]
+        return self.text_projection(pooled)
+
+
+class LoRA_AB:
+    """clip/custom_clip.py:139-217: (re-)initialise every lora_A, snapshot A/B of all layers, and
+    ``reset()`` the layers inside ``layer_range`` from the snapshot."""
+
+    def __init__(self, model, layer_range, init_method='xavier', lora_encoder='text'):
+        self.model = model
+        self.layer_range = layer_range
+        self.init_method = init_method
+        self.lora_encoder = lora_encoder
+        self.init_weights = []
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        if (self.init_method == 'xavier') or (self.init_method is None):
+            fn = init.xavier_normal_
+        elif self.init_method == 'gaussian':
+            fn = init.normal_
+        elif self.init_method == 'kaiming':
+            fn = init.kaiming_normal_
+        elif self.init_method == 'pretrained':
+            fn = None
+        else:
+            raise ValueError(f"Unsupported init_method: {self.init_method}")
+        if self.lora_encoder != 'image':
+            raise NotImplementedError("only lora_encoder='image' is implemented on the HIP path (SURVEY.md §8f-4)")
+        for layer in self.model.vision_model.encoder.layers:
+            self.initialize_layer_weights(layer, fn)
+
+    def initialize_layer_weights(self, layer, fn):
+        aq = layer.self_attn.q_proj.lora_A.default.weight
+        bq = layer.self_attn.q_proj.lora_B.default.weight
+        av = layer.self_attn.v_proj.lora_A.default.weight
+        bv = layer.self_attn.v_proj.lora_B.default.weight
+        # reference: `if self.init_method != (None or 'pretrained')` == `!= 'pretrained'` (custom_clip.py:184)
+        if self.init_method != 'pretrained':
+            with torch.no_grad():
+                fn(aq)   # q first, then v, layer 0..L-1: the reference's RNG draw order
+                fn(av)
+        self.init_weights.append((aq.detach().clone(), bq.detach().clone(), av.detach().clone(), bv.detach().clone()))
+
+    def reset(self):
+        layers = self.model.vision_model.encoder.layers
+        for i, layer in enumerate(layers):
+            if i in range(self.layer_range[0], self.layer_range[1] + 1):
+                aq, bq, av, bv = self.init_weights[i]
+                layer.self_attn.q_proj.lora_A.default.weight.data.copy_(aq)
+                layer.self_attn.q_proj.lora_B.default.weight.data.copy_(bq)
+                layer.self_attn.v_proj.lora_A.default.weight.data.copy_(av)
+                layer.self_attn.v_proj.lora_B.default.weight.data.copy_(bv)
+
+
+# ------------------------------------------------------------------------------- text side
+class _SyntheticTokenizer:
+    """Byte-level stand-in used only when no real CLIP tokenizer is available (synthetic-weights
+    runs): SOT 49406, EOT 49407 (the arg-max id, which the HF pooler keys on), zero padding."""
+    SOT, EOT, CTX = 49406, 49407, 77
+
+    def __call__(self, texts):
+        out = torch.zeros(len(texts), self.CTX, dtype=torch.long)
+        for i, t in enumerate(texts):
+            ids = [self.SOT] + [1 + (b % 49000) for b in t.encode("utf-8")][: self.CTX - 2] + [self.EOT]
+            out[i, :len(ids)] = torch.tensor(ids)
+        return out
+
+
+class PromptLearner(nn.Module):
+    """What the image-LoRA path uses of clip/custom_clip.py:220-372: the tokenized prompts
+    "a photo of a {class}." and ``reset_classnames``.  (Learnable context vectors belong to the
+    TPT prompt-tuning mode, which is out of scope — SURVEY.md §2.)"""
+
+    def __init__(self, tokenizer, classnames, ctx_init="a_photo_of_a"):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self.prompt_prefix = (ctx_init or "a photo of a").replace("_", " ")
+        self.reset_classnames(classnames, None)
+
+    def reset_classnames(self, classnames, arch):
+        names = [n.replace("_", " ") for n in classnames]
+        prompts = [self.prompt_prefix + " " + n + "." for n in names]
+        self.tokenized_prompts = self.tokenizer(prompts)
+        self.classnames = names
+        self.n_cls = len(names)
+
+    def reset(self):
+        pass
+
+
+def _build_clip(cfg, weights_dir, seed):
+    """-> (hf CLIPModel for the text tower, vision state (fp32 dict), tokenizer)."""
+    from transformers import CLIPConfig, CLIPModel
+    if weights_dir:
+        from transformers import CLIPTokenizer
+        model = CLIPModel.from_pretrained(weights_dir).float().eval()
+        tok = CLIPTokenizer.from_pretrained(weights_dir)
+        tokenizer = lambda texts: tok(texts, padding="max_length", max_length=77, truncation=True,
+                                      return_tensors="pt")["input_ids"]
+        sd = model.state_dict()
+        vis = {k: v for k, v in sd.items() if k.startswith("vision_model.") or k == "visual_projection.weight"}
+        vis = {k: v for k, v in vis.items() if "position_ids" not in k}
+        vis["logit_scale"] = sd["logit_scale"]
+        return model, vis, tokenizer
+    tw = 64 if cfg.width <= 128 else 512
+    conf = CLIPConfig(
+        vision_config=dict(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1,
+                           image_size=32, patch_size=16, projection_dim=cfg.embed),   # placeholder, unused
+        text_config=dict(hidden_size=tw, intermediate_size=4 * tw, num_hidden_layers=2 if cfg.width <= 128 else 12,
+                         num_attention_heads=max(1, tw // 64), eos_token_id=2, vocab_size=49408,
+                         max_position_embeddings=77, projection_dim=cfg.embed),
+        projection_dim=cfg.embed)
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(1234 + seed)
+    model = CLIPModel(conf).float().eval()
+    with torch.no_grad():   # non-degenerate random text tower (HF default init gives near-identical features)
+        for n, p in model.text_model.named_parameters():
+            if p.dim() >= 2 and "embedding" not in n:
+                p.normal_(0, 1.5 / math.sqrt(p.shape[-1]))
+        model.text_projection.weight.normal_(0, 1.0 / math.sqrt(tw))
+    torch.random.set_rng_state(gen_state)
+    return model, synth.vision_weights(cfg, seed), _SyntheticTokenizer()
+
+
+# ------------------------------------------------------------------------------- the model
+class ClipTestTimeTuning(nn.Module):
+    """clip/custom_clip.py:570-703 for lora_encoder='image'."""
+
+    def __init__(self, device, classnames, batch_size, criterion='cosine', arch="ViT-B/16", n_ctx=16, ctx_init=None,
+                 ctx_position='end', learned_cls=False, layer_range=[9, 11], init_method=None, lora_encoder='text',
+                 rank=16, max_views=64, max_classes=1000, weight_seed=0):
+        super().__init__()
+        if lora_encoder != 'image':
+            raise NotImplementedError(f"lora_encoder={lora_encoder!r}: only the image-LoRA path is built "
+                                      "(text-LoRA / prompt tuning are SURVEY.md §8f-4 / out of scope)")
+        self.device = torch.device(f"cuda:{device}" if isinstance(device, int) else device)
+        self.lora_encoder = lora_encoder
+        cfg = get_config(arch)
+        self.cfg = cfg = cfg.replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1])
+        self.layer_range = list(layer_range)
+        self.criterion = criterion
+        self.max_views = max(int(batch_size or 0), int(max_views))
+        self.max_classes = max(int(max_classes), len(classnames))
+        clip_model, vis_state, tokenizer = _build_clip(cfg, os.environ.get(CLIP_WEIGHTS_ENV), weight_seed)
+        self._vision_state = vis_state
+        self.image_encoder = VisionEncoder(cfg)
+        object.__setattr__(self.image_encoder, "_owner", self)
+        self.text_encoder = PromptEncoder(clip_model)
+        for p in self.text_encoder.parameters():
+            p.requires_grad_(False)
+        self.LoRA_AB = LoRA_AB(self.image_encoder, layer_range=layer_range, init_method=init_method, lora_encoder=lora_encoder)
+        ls = vis_state["logit_scale"]
+        self.logit_scale = torch.as_tensor(np.asarray(ls) if not isinstance(ls, torch.Tensor) else ls.detach().cpu()).float()
+        self.prompt_learner = PromptLearner(tokenizer, classnames, ctx_init)
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.engine = None
+        self._flat = None
+        self.text_features = None
+        self._text_dirty = True
+        self._opt_m = self._opt_v = self._snap = None
+        self.to(self.device)
+
+    # ---- parameter plumbing -----------------------------------------------------------------
+    def trainable_lora_parameters(self):
+        """The 4*nT tensors in the order of ttl.py:195-213."""
+        out = []
+        for i in range(self.layer_range[0], self.layer_range[1] + 1):
+            sa = self.image_encoder.vision_model.encoder.layers[i].self_attn
+            out += [sa.q_proj.lora_A.default.weight, sa.q_proj.lora_B.default.weight,
+                    sa.v_proj.lora_A.default.weight, sa.v_proj.lora_B.default.weight]
+        return out
+
+    def _ensure_engine(self):
+        params = self.trainable_lora_parameters()
+        dev = params[0].device
+        if dev.type != "cuda":
+            from ._lib import TtlError
+            raise TtlError("the model is on CPU: TTL's hot path only exists as HIP kernels (move it with .cuda())")
+        if self.engine is None or self.engine.device != dev:
+            if self.engine is not None:
+                self.engine.close()
+            self.engine = TTLEngine(self.cfg, self.max_views, self.max_classes, dev)
+            self.engine.load_weights(self._vision_state)
+            self._flat = None
+            self._text_dirty = True
+        # (re)alias the trained parameters onto one flat buffer the fused kernels can walk
+        off, ok = 0, self._flat is not None
+        if ok:
+            for p in params:
+                ok = ok and p.data_ptr() == self._flat.data_ptr() + 4 * off
+                off += p.numel()
+        if not ok:
+            flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params]).contiguous()
+            off = 0
+            for p in params:
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._flat = flat
+            self.engine.bind_lora(flat)
+            self._opt_m = torch.zeros_like(flat)
+            self._opt_v = torch.zeros_like(flat)
+            self._snap = None
+        if self._text_dirty:
+            with torch.no_grad():
+                self.text_features = self.get_text_features()
+            self.engine.set_text_features(self.text_features, float(self.logit_scale.exp()))
+            self._text_dirty = False
+        return self.engine
+
+    def snapshot_flat(self):
+        """Flat copy of LoRA_AB's snapshot for the trained layers (for the fused reset)."""
+        if self._snap is None:
+            parts = []
+            for i in range(self.layer_range[0], self.layer_range[1] + 1):
+                parts += [t.reshape(-1) for t in self.LoRA_AB.init_weights[i]]
+            self._snap = torch.cat(parts).to(self._flat.device, torch.float32).contiguous()
+        return self._snap
+
+    def _engine_forward(self, x, save):
+        eng = self._ensure_engine()
+        if x.shape[0] > eng.max_views:
+            raise ValueError(f"{x.shape[0]} views exceed the engine capacity {eng.max_views} (pass max_views=)")
+        return eng.forward(x, save=save)
+
+    # ---- reference surface ------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def LoRA_reset(self):
+        self.LoRA_AB.reset()
+
+    def reset(self):
+        self.prompt_learner.reset()
+
+    def reset_classnames(self, classnames, arch):
+        self.prompt_learner.reset_classnames(classnames, arch)
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        if len(classnames) > self.max_classes:
+            self.max_classes = len(classnames)
+            if self.engine is not None:
+                self.engine.close()
+                self.engine = None
+        self._text_dirty = True
+
+    def get_text_features(self):
+        dev = next(self.text_encoder.parameters()).device
+        t = self.text_encoder(self.prompt_learner.tokenized_prompts.to(dev))
+        t = t / t.norm(dim=-1, keepdim=True)
+        return torch.mean(torch.stack([t], dim=0), dim=0)
+
+    def image_features_of(self, image):
+        eng = self._ensure_engine()
+        _, f = eng.forward(image, save=False, want_features=True)
+        return f
+
+    def inference(self, image, label=None, coeff=None):
+        if coeff is not None:
+            raise NotImplementedError("coeff pooling (clip/custom_clip.py:682-684) is unused by ttl.py and not built")
+        self._ensure_engine()
+        params = self.trainable_lora_parameters()
+        # grad mode is off inside Function.forward, so decide here whether a graph is wanted
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _VitLogitsFn.apply(self, save, image, *params)
+
+    def forward(self, input, label=None, coeff=None):
+        if isinstance(input, tuple) or input.dim() == 2:
+            raise NotImplementedError("contrastive / directional prompt tuning branches do not exist in the "
+                                      "reference either (clip/custom_clip.py:696-701)")
+        return self.inference(input, label, coeff)
+
+
+def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, layer_range=[0, 11], init_method=None,
+             lora_encoder='text', rank=16, classnames=None, **kw):
+    """clip/custom_clip.py:706-723.  NOTE the reference drops ``rank`` here (always 16);
+    this build forwards it.  ``classnames`` may be given directly (the reference looks them up
+    from its own dataset tables, which are out of scope)."""
+    if classnames is None:
+        if test_set == 'bongard':
+            classnames = ['X', 'X'] if learned_cls else ['True', 'False']
+        else:
+            classnames = [f"class {i}" for i in range(1000)]
+    return ClipTestTimeTuning(device, classnames, None, arch=clip_arch, n_ctx=n_ctx, ctx_init=ctx_init,
+                              learned_cls=learned_cls, layer_range=layer_range, init_method=init_method,
+                              lora_encoder=lora_encoder, rank=rank, **kw)
+
+
+get_ttl = get_coop

@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference's deyo.py for the path TTL uses: ``DeYO`` (deyo.py:17-82),
+``softmax_entropy`` (:85-90) and ``forward_and_adapt_sar`` (:92-196).
+
+On a ``ttl_amd.custom_clip.ClipTestTimeTuning`` model the step is one enqueue of HIP kernels:
+forward -> fused entropy / selection / weighted loss + analytic dlogits -> truncated LoRA
+backward -> fused AdamW on the flat LoRA buffer.  The optimizer / scaler objects the reference
+passes in stay consistent: hyper-parameters are read from ``optimizer.param_groups``, Adam state
+lives in ``optimizer.state`` (so ``optimizer.load_state_dict(optim_state)`` at ttl.py:344 resets it
+exactly like in the reference), ``scaler.update()`` remains callable (bf16 needs no loss scale,
+non-finite gradients are skipped inside the AdamW kernel — the GradScaler contract).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def softmax_entropy(x: torch.Tensor) -> torch.Tensor:
+    """deyo.py:85-90."""
+    return -(x.softmax(1) * x.log_softmax(1)).sum(1)
+
+
+def _adam_hparams(optimizer, model):
+    """Check that ``optimizer`` is the AdamW of ttl.py:218 over this model's LoRA tensors and
+    return its hyper-parameters."""
+    params = model.trainable_lora_parameters()
+    got = [p for g in optimizer.param_groups for p in g["params"]]
+    if len(got) != len(params) or any(a is not b for a, b in zip(got, params)):
+        raise ValueError("optimizer must hold exactly the LoRA parameters of layer_range in the order of ttl.py:195-213")
+    g0 = optimizer.param_groups[0]
+    for g in optimizer.param_groups:
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if g[k] != g0[k]:
+                raise ValueError("per-group hyper-parameters differ; the fused step needs one setting")
+    if not isinstance(optimizer, torch.optim.AdamW) or g0.get("amsgrad", False) or g0.get("maximize", False):
+        raise ValueError("fused step implements torch.optim.AdamW (amsgrad=False) only")
+    return params, g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+
+
+def _adam_state(optimizer, model, params):
+    """Bind optimizer.state to the model's flat exp_avg / exp_avg_sq buffers; a cleared state
+    (after load_state_dict of the empty snapshot, ttl.py:344) zeroes them.  -> step count so far."""
+    m, v = model._opt_m, model._opt_v
+    st = optimizer.state
+    p0 = params[0]
+    fresh = (p0 not in st) or ("exp_avg" not in st[p0]) or (st[p0]["exp_avg"].data_ptr() != m.data_ptr())
+    if fresh:
+        m.zero_()
+        v.zero_()
+        off = 0
+        for p in params:
+            n = p.numel()
+            st[p] = {"step": torch.tensor(0.0), "exp_avg": m[off:off + n].view(p.shape),
+                     "exp_avg_sq": v[off:off + n].view(p.shape)}
+            off += n
+        return 0
+    return int(st[p0]["step"].item())
+
+
+def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin, margin, targets=None, flag=True,
+                          group=None):
+    """deyo.py:92-196 on the HIP path.  Returns (outputs, backward, final_backward)."""
+    if targets is not None:
+        raise NotImplementedError("targets / pseudo-label accounting is not part of the TTL hot path")
+    if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
+        raise NotImplementedError("PLPD filtering (deyo.py:115-151) is the next row of SURVEY.md §8f-3")
+    eng = model._ensure_engine()
+    if not flag:
+        return eng.forward(x, save=False)
+    params, lr, betas, eps, wd = _adam_hparams(optimizer, model)
+    step = _adam_state(optimizer, model, params)
+    outputs = eng.forward(x, save=True)                                          # deyo.py:97
+    mode = _lib.TTL_SEL_TOPK if getattr(args, "filter_ent", 0) else _lib.TTL_SEL_LE_THRESH
+    reweight = float(getattr(args, "reweight_ent", 1))
+    L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
+                                reweight=reweight)                               # deyo.py:102-108,159-181
+    eng.backward(L["dlogits"])                                                   # deyo.py:185-186
+    for p, gslice in zip(params, _grad_views(eng, params)):
+        p.grad = gslice
+    eng.adamw_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd,
+                   n_selected=L["n"])                                            # deyo.py:187
+    n = int(L["n"].item())                                                       # the only host sync of the step
+    if n:
+        for p in params:
+            optimizer.state[p]["step"] += 1
+    if scaler is not None and hasattr(scaler, "update") and getattr(scaler, "is_enabled", lambda: False)():
+        pass  # nothing was scaled: there is no inf/nan bookkeeping to feed scaler.update() with
+    return outputs, n, n
+
+
+def _grad_views(eng, params):
+    off = 0
+    for p in params:
+        yield eng.grads[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+
+
+class DeYO(nn.Module):
+    """deyo.py:17-82."""
+
+    def __init__(self, model, args, optimizer, scaler, steps=1, episodic=False, deyo_margin=0.5 * math.log(1000),
+                 margin_e0=0.4 * math.log(1000)):
+        super().__init__()
+        self.model = model
+        self.optimizer = optimizer
+        self.scaler = scaler
+        self.args = args
+        self.steps = steps
+        self.episodic = episodic
+        self.deyo_margin = deyo_margin
+        self.margin_e0 = margin_e0
+
+    def forward(self, x, iter_=None, targets=None, flag=True, group=None):
+        if targets is not None:
+            raise NotImplementedError("targets / pseudo-label accounting is not part of the TTL hot path")
+        outputs = backward = final_backward = None
+        for _ in range(self.steps):
+            r = forward_and_adapt_sar(x, iter_, self.model, self.args, self.optimizer, self.scaler, self.deyo_margin,
+                                      self.margin_e0, targets, flag, group)
+            if flag:
+                outputs, backward, final_backward = r
+            else:
+                outputs = r
+        return (outputs, backward, final_backward) if flag else outputs

@@ -1,0 +1,70 @@
+"""Sharded evaluation loop — this build's counterpart of ``test_time_adapt_eval`` (ttl.py:300-363).
+
+Test images are independent episodes (LoRA + Adam state are reset before every image,
+ttl.py:338-344), so they shard embarrassingly: rank r of W takes the indices i with i % W == r, runs
+the single-GPU loop, and ONE all-reduce(SUM) of [top1 hits, top5 hits, count] (3 x int64) per
+dataset produces the accuracy (RCCL over xGMI on GPUs; gloo in the CPU tests).  There is no other
+collective on the path: nothing about an episode crosses GPUs.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def shard_indices(n_items, rank, world):
+    """Strided partition: invariant per-index work assignment, balanced to within one item."""
+    return range(rank, n_items, world)
+
+
+def topk_hits(logits, target, ks=(1, 5)):
+    """utils/tools.py:88-102 ``accuracy`` as integer hit counts (device tensors, no host sync)."""
+    k = min(max(ks), logits.shape[1])
+    pred = logits.topk(k, dim=1).indices                        # [B,k]
+    eq = pred.eq(target.view(-1, 1))
+    return [eq[:, :min(kk, k)].any(dim=1).sum() for kk in ks]
+
+
+def evaluate_sharded(predict_fn, n_items, label_fn, rank=0, world=1, device="cpu", group=None):
+    """predict_fn(i) -> logits [1,K] after adaptation on test item i; label_fn(i) -> int.
+    Returns dict(top1, top5, count, hits1, hits5) — identical on every rank."""
+    acc = torch.zeros(3, dtype=torch.int64, device=device)      # [hits1, hits5, count]
+    for i in shard_indices(n_items, rank, world):
+        logits = predict_fn(i)
+        tgt = torch.tensor([label_fn(i)], device=logits.device)
+        h1, h5 = topk_hits(logits, tgt)
+        acc[0] += h1.to(acc.device)
+        acc[1] += h5.to(acc.device)
+        acc[2] += 1
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # C1: the only collective of the path
+    hits1, hits5, count = (int(v) for v in acc.tolist())
+    return dict(hits1=hits1, hits5=hits5, count=count,
+                top1=100.0 * hits1 / max(count, 1), top5=100.0 * hits5 / max(count, 1))
+
+
+class EpisodeRunner:
+    """Fused per-image episode on a ``ClipTestTimeTuning`` model: reset -> n_updates x (forward,
+    loss, LoRA backward, AdamW) -> adapted 1-view inference, as one enqueue (ttl_episode)."""
+
+    def __init__(self, model, args):
+        self.model = model
+        self.args = args
+        self.eng = model._ensure_engine()
+        self.snap = model.snapshot_flat()
+        deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
+        self.kw = dict(
+            n_updates=(args.tta_steps ** 2 if deyo else args.tta_steps),
+            objective="deyo" if deyo else "tpt",
+            mode=1 if getattr(args, "filter_ent", 0) else 0, rho=args.selection_p, margin=args.deyo_margin_e0,
+            reweight=float(getattr(args, "reweight_ent", 1)), lr=args.lr)
+
+    def __call__(self, views):
+        """views [N,3,S,S] (view 0 = the un-augmented image) -> logits [1,K] with adapted weights."""
+        m = self.model
+        return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
