@@ -90,12 +90,12 @@ struct ttl_ctx {
     bf16_t* patches; float* h;  // running residual stream
     float* h_out[8];             // outputs of trained layers (h_out[i] = input of the next one)
     bf16_t *x1, *qkv, *attn, *x2, *g;
-    float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits;
+    float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits, *head_te, *head_td;
     // backward scratch
     float *dh, *dh2, *dx; bf16_t *dh16, *dbig, *dattn, *dqkv;
     float* wg_partial;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
-    bool saved = false; int saved_n = 0;
+    bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
     bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -159,10 +159,10 @@ void set_geometry(ttl_ctx* c, const ttl_config* k) {
 struct Prof {
     ttl_ctx* c; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     Prof(ttl_ctx* c_, int cls_, hipStream_t s_) : c(c_), cls(cls_), s(s_) {
-        if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+        if (c->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~Prof() {
-        if (c->prof) { hipEventRecord(b, s); c->prof_events.push_back({cls, {a, b}}); }
+        if (c->prof) { (void)hipEventRecord(b, s); c->prof_events.push_back({cls, {a, b}}); }
     }
 };
 
@@ -238,6 +238,7 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->x2, M * D, false); ALLOC(c->g, M * F, false);
     ALLOC(c->cls_mean, N, false); ALLOC(c->cls_rstd, N, false); ALLOC(c->ycls, N * D, false); ALLOC(c->feat, N * E, false);
     ALLOC(c->logits, N * k->max_classes, false); ALLOC(c->dlogits, N * k->max_classes, false);
+    ALLOC(c->head_te, N * E, false); ALLOC(c->head_td, N * D, false);
     ALLOC(c->dh, M * D, false); ALLOC(c->dh2, M * D, false); ALLOC(c->dx, M * D, false);
     ALLOC(c->dh16, M * D, false); ALLOC(c->dbig, M * F, false); ALLOC(c->dattn, M * D, false);
     ALLOC(c->dqkv, M * c->ldwt, true);
@@ -251,9 +252,9 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
 
 void ttl_ctx_destroy(ttl_ctx* c) {
     if (!c) return;
-    hipDeviceSynchronize();
-    for (auto& pe : c->prof_events) { hipEventDestroy(pe.second.first); hipEventDestroy(pe.second.second); }
-    for (void* p : c->allocs) hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+    for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
 
@@ -263,7 +264,7 @@ static int upload(ttl_ctx* c, const float* data, size_t count, float** tmp) {
     hipError_t e = hipMalloc(&q, count * sizeof(float));
     if (e != hipSuccess) return fail(TTL_ENOMEM, "staging hipMalloc failed: %s", hipGetErrorString(e));
     e = hipMemcpy(q, data, count * sizeof(float), hipMemcpyDefault);
-    if (e != hipSuccess) { hipFree(q); return fail((int)e, "weight copy failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(q); return fail((int)e, "weight copy failed: %s", hipGetErrorString(e)); }
     *tmp = (float*)q;
     return 0;
 }
@@ -293,7 +294,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
             hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)D, l.wqkv + (size_t)which * D * c->ldw, c->ldw, s);
             if (e == hipSuccess && l.trained) e = launch_transpose_f32_bf16(tmp, (int)D, (int)D, l.wqkvT + (size_t)which * D, c->ldwt, s);
             if (e == hipSuccess) e = hipDeviceSynchronize();
-            hipFree(tmp);
+            (void)hipFree(tmp);
             if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
             l.loaded |= bit;
             return 0;
@@ -304,7 +305,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
             hipError_t e = launch_cast_f32_bf16(tmp, dst, count, s);
             if (e == hipSuccess && dstT) e = launch_transpose_f32_bf16(tmp, (int)rows, (int)cols, dstT, (int)rows, s);
             if (e == hipSuccess) e = hipDeviceSynchronize();
-            hipFree(tmp);
+            (void)hipFree(tmp);
             if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
             l.loaded |= bit;
             return 0;
@@ -335,7 +336,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
         if ((rc = upload(c, data, count, &tmp))) return rc;
         hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)kk, c->wpatch, c->Kp, s);
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        hipFree(tmp);
+        (void)hipFree(tmp);
         if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
         c->head_loaded |= HW_PATCH;
         return 0;
@@ -400,6 +401,7 @@ static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* l
     a.ln_g = c->postg; a.ln_b = c->postb; a.eps = c->c.ln_eps;
     a.WpT = c->wpT; a.Wp = c->wp; a.tfeat = c->tfeat; a.tfeatT = c->tfeatT; a.scale = c->scale;
     a.cls_mean = c->cls_mean; a.cls_rstd = c->cls_rstd; a.y = c->ycls; a.f = c->feat; a.logits = logits; a.feats_out = feats_out;
+    a.tmp_e = c->head_te; a.tmp_d = c->head_td;
     return a;
 }
 
@@ -415,8 +417,14 @@ static int lora_refresh(ttl_ctx* c, hipStream_t s) {
     return 0;
 }
 
-int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_out, float* feats_out, void* stream) {
-    if (!c || !x) return fail(TTL_EINVAL, "null argument");
+// from_layer == 0: the whole tower.  from_layer == layer_lo: resume from the residual stream the
+// last full forward left at the input of the first trained layer (c->h, untouched since): the
+// frozen layers below it do not depend on the LoRA parameters, so for the same views the result
+// is identical — used for the later updates of a multi-step episode and for the adapted
+// inference on view 0 (rows 0..T-1 of that buffer).
+static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_layer, float* logits_out, float* feats_out,
+                        void* stream) {
+    if (!c || (!x && from_layer == 0)) return fail(TTL_EINVAL, "null argument");
     if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
     if (c->K < 1) return fail(TTL_ESTATE, "ttl_set_text_features has not been called");
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
@@ -425,24 +433,30 @@ int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_o
     hipStream_t s = (hipStream_t)stream;
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H;
     if ((rc = lora_refresh(c, s))) return rc;
-    // patch embedding: im2col -> GEMM (+pos) ; CLS rows
-    {
-        Prof p(c, 3, s);
-        HIP_TRY(launch_im2col(x, c->patches, n, c->S, c->P, c->Kp, s));
-        HIP_TRY(launch_cls_rows(c->h, c->cls, c->pos, n, T, D, s));
-    }
-    {
-        GemmArgs a = {};
-        a.A = c->patches; a.lda = c->Kp; a.B = c->wpatch; a.ldb = c->Kp; a.M = n * c->G2; a.N = D; a.K = c->Kp;
-        a.C = c->h; a.ldc = D; a.pos = c->pos; a.G2 = c->G2; a.T = T;
-        if ((rc = gemm(c, EPI_PATCH, a, s))) return rc;
-    }
     float* h = c->h;
-    {
-        Prof p(c, 3, s);
-        HIP_TRY(launch_layernorm(h, D, c->preg, c->preb, h, nullptr, 0, nullptr, nullptr, M, D, c->c.ln_eps, s));
+    if (from_layer == 0) {
+        // patch embedding: im2col -> GEMM (+pos) ; CLS rows
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_im2col(x, c->patches, n, c->S, c->P, c->Kp, s));
+            HIP_TRY(launch_cls_rows(c->h, c->cls, c->pos, n, T, D, s));
+        }
+        {
+            GemmArgs a = {};
+            a.A = c->patches; a.lda = c->Kp; a.B = c->wpatch; a.ldb = c->Kp; a.M = n * c->G2; a.N = D; a.K = c->Kp;
+            a.C = c->h; a.ldc = D; a.pos = c->pos; a.G2 = c->G2; a.T = T;
+            if ((rc = gemm(c, EPI_PATCH, a, s))) return rc;
+        }
+        {
+            Prof p(c, 3, s);
+            HIP_TRY(launch_layernorm(h, D, c->preg, c->preb, h, nullptr, 0, nullptr, nullptr, M, D, c->c.ln_eps, s));
+        }
+        c->stream_views = n;
+    } else if (from_layer != c->c.layer_lo || n > c->stream_views) {
+        return fail(TTL_ESTATE, "cannot resume at layer %d for %d views (stream holds %d views at layer %d)", from_layer, n,
+                    c->stream_views, c->c.layer_lo);
     }
-    for (int i = 0; i < c->L; ++i) {
+    for (int i = from_layer; i < c->L; ++i) {
         Layer& l = c->layers[i];
         const bool tr = l.trained;          // LoRA path active (B == 0 forever in the other layers, Q10)
         const bool sv = tr && save;
@@ -507,6 +521,10 @@ int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_o
     return 0;
 }
 
+int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_out, float* feats_out, void* stream) {
+    return forward_impl(c, x, n, save, 0, logits_out, feats_out, stream);
+}
+
 int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double rho, float thresh, float margin, float reweight,
                             float* H_out, int64_t* idx_out, int* n_out, float* loss_out, float* dlogits_out, void* stream) {
     if (!logits || !dlogits_out || !n_out) return fail(TTL_EINVAL, "null argument");
@@ -517,7 +535,7 @@ int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double 
     HIP_TRY(hipMallocAsync((void**)&scratch, cnt * sizeof(float), s));
     hipError_t e = launch_entropy_loss(logits, N, K, 0, mode, rho, thresh, margin, reweight, 0, H_out, (long long*)idx_out, n_out,
                                        loss_out, dlogits_out, scratch, s);
-    hipFreeAsync(scratch, s);
+    (void)hipFreeAsync(scratch, s);
     HIP_TRY(e);
     return 0;
 }
@@ -532,7 +550,7 @@ int ttl_tpt_select_loss(const float* logits, int N, int K, double rho, int reuse
     HIP_TRY(hipMallocAsync((void**)&scratch, cnt * sizeof(float), s));
     hipError_t e = launch_entropy_loss(logits, N, K, 1, TTL_SEL_TOPK, rho, 0.f, 0.f, 0.f, reuse_idx, H_out, (long long*)idx_io, n_io,
                                        loss_out, dlogits_out, scratch, s);
-    hipFreeAsync(scratch, s);
+    (void)hipFreeAsync(scratch, s);
     HIP_TRY(e);
     return 0;
 }
@@ -631,7 +649,9 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     int rc;
     HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
     for (int u = 0; u < a->n_updates; ++u) {
-        if ((rc = ttl_vit_forward(c, a->x, a->n_views, 1, (u == 0) ? a->logits0_out : nullptr, nullptr, stream))) return rc;
+        if ((rc = forward_impl(c, a->x, a->n_views, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr,
+                               stream)))
+            return rc;
         {
             Prof p(c, 5, s);
             HIP_TRY(launch_entropy_loss(c->logits, a->n_views, c->K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
@@ -645,7 +665,10 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
                                  a->weight_decay, u + 1, c->n_buf, s));
         }
     }
-    return ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
+    if (a->n_updates < 1) return ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
+    // adapted prediction on view 0 (ttl.py:350-352): layers below layer_lo are unchanged by the
+    // update, so resume from the stream row block of view 0
+    return forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------ kernel-level entry points
@@ -724,8 +747,8 @@ int ttl_profile_read(ttl_ctx* c, double ms[TTL_NCLASS], long long launches[TTL_N
             c->prof_ms[pe.first] += t;
             c->prof_n[pe.first] += 1;
         }
-        hipEventDestroy(pe.second.first);
-        hipEventDestroy(pe.second.second);
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
     }
     c->prof_events.clear();
     for (int i = 0; i < TTL_NCLASS; ++i) {

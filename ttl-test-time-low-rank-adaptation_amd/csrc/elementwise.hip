@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                     float* __restrict__ o32, bf16_t* __restrict__ o16, int rows, int D) {
+                                                     float* __restrict__ o32, bf16_t* __restrict__ o16, int rows, int D,
+                                                     long long xs, long long os) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         int c = lane + 64 * i;
         if (c < nch) {
             float4 d = *(const float4*)(dy + (size_t)row * D + 4 * c);
-            float4 xv = *(const float4*)(x + (size_t)row * D + 4 * c);
+            float4 xv = *(const float4*)(x + (size_t)row * xs + 4 * c);
             float4 g = *(const float4*)(gamma + 4 * c);
             dxh[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
             xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
@@ -161,11 +162,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < LN_MAXC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
-            float4 r = dres ? *(const float4*)(dres + (size_t)row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 r = dres ? *(const float4*)(dres + (size_t)row * os + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
-            if (o32) *(float4*)(o32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (o16) *(u32x2*)(o16 + (size_t)row * D + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+            if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
+            if (o16) *(u32x2*)(o16 + (size_t)row * os + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
         }
     }
 }
@@ -215,10 +216,10 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16, int rows,
-                                int D, hipStream_t s) {
+                                int D, hipStream_t s, long long x_stride, long long o_stride) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
-                       out_bf16, rows, D);
+                       out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D);
     return hipGetLastError();
 }
 

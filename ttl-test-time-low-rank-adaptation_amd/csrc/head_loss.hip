@@ -31,90 +31,63 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
-// one block per view
-__global__ __launch_bounds__(HB) void head_fwd_kernel(HeadArgs a) {
+// ---- head forward: (LayerNorm of the CLS rows is launch_layernorm) -> projection -> logits
+// grid (ceil(E/HB), n): thread e accumulates over D with coalesced WpT reads, y row staged in LDS
+__global__ __launch_bounds__(HB) void head_proj_kernel(HeadArgs a) {
     extern __shared__ float sm[];
-    float* sy = sm;            // [D]
-    float* sf = sm + a.D;      // [E]
-    __shared__ float red[HB / 64];
-    const int v = blockIdx.x, tid = threadIdx.x;
-    const float* x = a.h + (size_t)v * a.T * a.D;
-    float s = 0.f;
-    for (int d = tid; d < a.D; d += HB) s += x[d];
-    const float mu = block_sum(s, red) / a.D;
-    float q = 0.f;
-    for (int d = tid; d < a.D; d += HB) { float c = x[d] - mu; q += c * c; }
-    const float rs = rsqrtf(block_sum(q, red) / a.D + a.eps);
-    for (int d = tid; d < a.D; d += HB) {
-        float y = (x[d] - mu) * rs * a.ln_g[d] + a.ln_b[d];
-        sy[d] = y;
-        a.y[(size_t)v * a.D + d] = y;
-    }
-    if (tid == 0) { a.cls_mean[v] = mu; a.cls_rstd[v] = rs; }
+    const int v = blockIdx.y, e = blockIdx.x * HB + threadIdx.x;
+    for (int d = threadIdx.x; d < a.D; d += HB) sm[d] = a.y[(size_t)v * a.D + d];
     __syncthreads();
-    float nn = 0.f;
-    for (int e = tid; e < a.E; e += HB) {
-        float acc = 0.f;
-        for (int d = 0; d < a.D; ++d) acc = fmaf(sy[d], a.WpT[(size_t)d * a.E + e], acc);
-        sf[e] = acc;
-        a.f[(size_t)v * a.E + e] = acc;
-        if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
-        nn += acc * acc;
-    }
-    const float inv = a.scale / sqrtf(block_sum(nn, red));
-    for (int k = tid; k < a.K; k += HB) {
-        float acc = 0.f;
-        for (int e = 0; e < a.E; ++e) acc = fmaf(sf[e], a.tfeatT[(size_t)e * a.K + k], acc);
-        a.logits[(size_t)v * a.K + k] = acc * inv;
-    }
+    if (e >= a.E) return;
+    float acc = 0.f;
+    for (int d = 0; d < a.D; ++d) acc = fmaf(sm[d], a.WpT[(size_t)d * a.E + e], acc);
+    a.f[(size_t)v * a.E + e] = acc;
+    if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
 }
-
-__global__ __launch_bounds__(HB) void head_bwd_kernel(HeadArgs a, const float* __restrict__ dlogits,
-                                                      float* __restrict__ dh, bf16_t* __restrict__ dh16) {
+// grid (ceil(K/HB), n): z[v][k] = scale * <f/||f||, t_k>
+__global__ __launch_bounds__(HB) void head_logits_kernel(HeadArgs a) {
     extern __shared__ float sm[];
-    float* sdz = sm;                 // [K]
-    float* sdf = sm + a.K;           // [E]
-    float* sdy = sm + a.K + a.E;     // [D]
     __shared__ float red[HB / 64];
-    const int v = blockIdx.x, tid = threadIdx.x;
-    for (int k = tid; k < a.K; k += HB) sdz[k] = dlogits[(size_t)v * a.K + k];
-    __syncthreads();
-    const float* f = a.f + (size_t)v * a.E;
+    const int v = blockIdx.y, k = blockIdx.x * HB + threadIdx.x;
     float nn = 0.f;
-    for (int e = tid; e < a.E; e += HB) nn += f[e] * f[e];
+    for (int e = threadIdx.x; e < a.E; e += HB) { float t = a.f[(size_t)v * a.E + e]; sm[e] = t; nn += t * t; }
+    const float inv = a.scale / sqrtf(block_sum(nn, red));
+    if (k >= a.K) return;
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e) acc = fmaf(sm[e], a.tfeatT[(size_t)e * a.K + k], acc);
+    a.logits[(size_t)v * a.K + k] = acc * inv;
+}
+// ---- head backward
+// grid (ceil(E/HB), n): dfh[v][e] = scale * sum_k dz[v][k] t[k][e]
+__global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* __restrict__ dz) {
+    extern __shared__ float sm[];
+    const int v = blockIdx.y, e = blockIdx.x * HB + threadIdx.x;
+    for (int k = threadIdx.x; k < a.K; k += HB) sm[k] = dz[(size_t)v * a.K + k];
+    __syncthreads();
+    if (e >= a.E) return;
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) acc = fmaf(sm[k], a.tfeat[(size_t)k * a.E + e], acc);
+    a.tmp_e[(size_t)v * a.E + e] = acc * a.scale;
+}
+// grid (ceil(D/HB), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
+__global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
+    extern __shared__ float sm[];
+    __shared__ float red[HB / 64];
+    const int v = blockIdx.y, d = blockIdx.x * HB + threadIdx.x;
+    const float* f = a.f + (size_t)v * a.E;
+    const float* dfh = a.tmp_e + (size_t)v * a.E;
+    float nn = 0.f;
+    for (int e = threadIdx.x; e < a.E; e += HB) nn += f[e] * f[e];
     const float nrm = sqrtf(block_sum(nn, red));
     float dot = 0.f;
-    for (int e = tid; e < a.E; e += HB) {
-        float acc = 0.f;
-        for (int k = 0; k < a.K; ++k) acc = fmaf(sdz[k], a.tfeat[(size_t)k * a.E + e], acc);
-        acc *= a.scale;               // d/df̂
-        sdf[e] = acc;
-        dot += acc * (f[e] / nrm);
-    }
+    for (int e = threadIdx.x; e < a.E; e += HB) dot += dfh[e] * (f[e] / nrm);
     dot = block_sum(dot, red);
-    for (int e = tid; e < a.E; e += HB) sdf[e] = (sdf[e] - (f[e] / nrm) * dot) / nrm;  // d/df
+    for (int e = threadIdx.x; e < a.E; e += HB) sm[e] = (dfh[e] - (f[e] / nrm) * dot) / nrm;
     __syncthreads();
-    // dy = df · Wp ; then LayerNorm backward on the CLS row
-    const float* x = a.h + (size_t)v * a.T * a.D;
-    const float mu = a.cls_mean[v], rs = a.cls_rstd[v];
-    float s1 = 0.f, s2 = 0.f;
-    for (int d = tid; d < a.D; d += HB) {
-        float acc = 0.f;
-        for (int e = 0; e < a.E; ++e) acc = fmaf(sdf[e], a.Wp[(size_t)e * a.D + d], acc);
-        float dxh = acc * a.ln_g[d];
-        float xh = (x[d] - mu) * rs;
-        sdy[d] = dxh;
-        s1 += dxh;
-        s2 += dxh * xh;
-    }
-    const float m1 = block_sum(s1, red) / a.D;
-    const float m2 = block_sum(s2, red) / a.D;
-    for (int d = tid; d < a.D; d += HB) {
-        float xh = (x[d] - mu) * rs;
-        float o = rs * (sdy[d] - m1 - xh * m2);
-        dh[(size_t)v * a.T * a.D + d] = o;
-        if (dh16) dh16[(size_t)v * a.T * a.D + d] = f32_to_bf16(o);
-    }
+    if (d >= a.D) return;
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e) acc = fmaf(sm[e], a.Wp[(size_t)e * a.D + d], acc);
+    a.tmp_d[(size_t)v * a.D + d] = acc;
 }
 
 // ---- loss, pass 1: one block per view: row softmax statistics -> H_i, lse_i
@@ -300,15 +273,22 @@ __global__ void reset_kernel(float* __restrict__ p, const float* __restrict__ sn
 }  // namespace
 
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
-    size_t sm = (size_t)(a.D + a.E) * sizeof(float);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(n), dim3(HB), sm, s, a);
+    hipError_t e = launch_layernorm(a.h, (long long)a.T * a.D, a.ln_g, a.ln_b, a.y, nullptr, 0, a.cls_mean, a.cls_rstd, n, a.D,
+                                    a.eps, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(head_proj_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.D * sizeof(float), s, a);
+    hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, bf16_t* dh16, int n, hipStream_t s) {
-    size_t sm = (size_t)(a.K + a.E + a.D) * sizeof(float);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(n), dim3(HB), sm, s, a, dlogits, dh, dh16);
-    return hipGetLastError();
+    hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
+    hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // LayerNorm backward on the CLS rows, written straight into the (pre-zeroed) stream gradient
+    return launch_layernorm_bwd(a.tmp_d, a.h, a.cls_mean, a.cls_rstd, a.ln_g, nullptr, dh, dh16, n, a.D, s,
+                                (long long)a.T * a.D, (long long)a.T * a.D);
 }
 
 // scratch layout (floats): [0,N) lse | [N,2N) coef | [2N,2N+1) nsel(int) | [2N+4, 2N+4+N) H (if H_out null)

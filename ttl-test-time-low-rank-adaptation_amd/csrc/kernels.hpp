@@ -46,9 +46,10 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
                             float* y_f32, bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
                             int D, float eps, hipStream_t s);
 // dx = LN-backward(dy; x, mean, rstd, gamma); out_f32 = dres + dx; out_bf16 = bf16(out_f32)
+// x_stride / o_stride: row pitch (elements) of x and of the outputs (D when contiguous)
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16,
-                                int rows, int D, hipStream_t s);
+                                int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
@@ -70,6 +71,7 @@ struct HeadArgs {
     float* cls_mean; float* cls_rstd; float* y; float* f; // saves [n],[n],[n,D],[n,E]
     float* logits;         // [n,K]
     float* feats_out;      // optional [n,E]
+    float* tmp_e; float* tmp_d;  // scratch [n,E], [n,D] (backward)
 };
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s);
 // dlogits [n,K] -> dh rows n*T (CLS) fp32 + bf16 copy; other rows are NOT touched
