@@ -8,30 +8,51 @@
 //     stages, next tile's DMA in flight under the current tile's MFMAs
 //   * LDS image is lane-linear (DMA constraint), bank conflicts removed by XOR-swizzling the
 //     SOURCE chunk and the ds_read_b128 chunk with the same involution (guide rule 21)
-//   * the weight tile is the MFMA A operand with its rows permuted so that every lane ends up
-//     with 16 CONTIGUOUS output columns -> 64 B (fp32) / 32 B (bf16) stores per lane per row
+//   * the weight tile's rows are permuted in LDS (physical row 16*nt + i of a 64-column slab holds
+//     output column 4*i + nt) so that a lane's four n-subtile accumulators are 4 CONTIGUOUS output
+//     columns: every store instruction writes 4 rows x 256 B (fp32) / 128 B (bf16) of whole lines
 //   * 1-D grid, XCD-aware tile order (n fastest: the A panel of a row tile stays in one L2)
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace {
 
-constexpr int BN = 128;
 constexpr int BK = 64;
 
-template <int BM, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
+// compile-time unrolled scheduling hints: NP x { MFMA x MPER, (first NP0 rounds) DS_READ x DPER, VMEM x 1 }
+template <int I, int NP, int NP0, int MPER, int DPER>
+struct SchedLoop {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
+        if constexpr (I < NP0) __builtin_amdgcn_sched_group_barrier(0x100, DPER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        SchedLoop<I + 1, NP, NP0, MPER, DPER>::run();
+    }
+};
+template <int NP, int NP0, int MPER, int DPER>
+struct SchedLoop<NP, NP, NP0, MPER, DPER> {
+    static __device__ __forceinline__ void run() {}
+};
+
+// BM x (64*WNW) block tile, WMW x WNW waves, every wave owns (BM/WMW) x 64 outputs.
+template <int BM, int WMW, int WNW, int EPI>
+__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW >= 8) ? 2 : 2) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WM = BM / 2;       // rows per wave
-    constexpr int MT = WM / 16;      // 16-row sub-tiles per wave
-    constexpr int NA = BM * 8 / 256; // DMA instructions per thread for the A tile
-    constexpr int NB = BN * 8 / 256;
+    constexpr int NTHR = 64 * WMW * WNW;
+    constexpr int BN = 64 * WNW;
+    constexpr int WM = BM / WMW;      // rows per wave
+    constexpr int MT = WM / 16;       // 16-row sub-tiles per wave
+    constexpr int NA = BM * 8 / NTHR; // DMA instructions per thread for the A tile
+    constexpr int NB = BN * 8 / NTHR;
+    static_assert(WM % 16 == 0 && (BM * 8) % NTHR == 0 && (BN * 8) % NTHR == 0, "tile shape");
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int STAGE = A_BYTES + BN * BK * 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int li = lane & 15, lg = lane >> 4;
 
     const int ntn = a.N / BN;
@@ -45,37 +66,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     const bf16_t* bsrc[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int q = i * 256 + tid, r = q >> 3, p = q & 7;
+        int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int gr = min(row0 + r, M - 1);
         asrc[i] = a.A + (size_t)gr * a.lda + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        int q = i * 256 + tid, r = q >> 3, p = q & 7;
-        int c = p ^ (((r >> 1) & 1) | (((r >> 4) & 3) << 1));
-        bsrc[i] = a.B + (size_t)(col0 + r) * a.ldb + c * 8;
+        int q = i * NTHR + tid, r = q >> 3, p = q & 7;
+        int c = p ^ ((r >> 1) & 7);
+        int n = (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);  // physical LDS row r holds this output column
+        bsrc[i] = a.B + (size_t)(col0 + n) * a.ldb + c * 8;
     }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + (i * 256 + wave * 64) * 16),
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + (i * NTHR + wave * 64) * 16),
                                              16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i] + kt * BK),
-                                             LDS_PTR(base + A_BYTES + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                                             LDS_PTR(base + A_BYTES + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     };
 
     // ---- per-lane fragment addresses ----
     const int swA = (li >> 1) & 7;
-    const int swW = ((li >> 1) & 1) | (((li >> 2) & 3) << 1);
     int offA[MT], offW[4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) offA[mt] = (wm * WM + mt * 16 + li) * 128;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) offW[nt] = A_BYTES + (wn * 64 + 16 * (li >> 2) + 4 * nt + (li & 3)) * 128;
+    for (int nt = 0; nt < 4; ++nt) offW[nt] = A_BYTES + (wn * 64 + 16 * nt + li) * 128;
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -84,133 +105,143 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / BK;
+    constexpr int NP = NA + NB;            // DMA pieces per thread per K-tile
+    constexpr int NP0 = (NP + 1) / 2;      // issued under the first 32-deep half, the rest under the second
+    auto stage_piece = [&](int i, int kt, char* base) {
+        if (i < NA)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i - NA] + kt * BK),
+                                             LDS_PTR(base + A_BYTES + ((i - NA) * NTHR + wave * 64) * 16), 16, 0, 0);
+    };
+    auto load_frags = [&](const char* base, int s, bf16x8 (&xf)[MT], bf16x8 (&wf)[4]) {
+        const int cA = ((4 * s + lg) ^ swA) << 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(base + offA[mt] + cA);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(base + offW[nt] + cA);
+    };
+    auto mma = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+    };
     stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // steady state: tile kt is consumed while tile kt+1's DMA is issued BETWEEN the MFMAs (the
+    // matrix pipe never waits behind a burst of DMA issue); the last tile is peeled (no prefetch)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
         __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* base = smem + (kt & 1) * STAGE;
+        char* nxt = smem + ((kt + 1) & 1) * STAGE;
+        bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+        load_frags(base, 0, xf0, wf0);
+        load_frags(base, 1, xf1, wf1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int cA = ((4 * s + lg) ^ swA) << 4;
-            const int cW = ((4 * s + lg) ^ swW) << 4;
-            bf16x8 xf[MT], wf[4];
+        for (int i = 0; i < NP0; ++i) stage_piece(i, kt + 1, nxt);
+        mma(xf0, wf0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(base + offA[mt] + cA);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(base + offW[nt] + cW);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-        }
+        for (int i = NP0; i < NP; ++i) stage_piece(i, kt + 1, nxt);
+        mma(xf1, wf1);
+        // pin the interleave: fragments of the first half, then {MFMAs, one DMA piece, a few reads}
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
+        SchedLoop<0, NP, NP0, (2 * MT * 4) / NP, (MT + 4 + NP0 - 1) / NP0>::run();
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * 4 - NP * ((2 * MT * 4) / NP), 0);
     }
-
-    // ---- epilogue: lane (lg, li) owns rows m(mt) and 16 contiguous columns n0 .. n0+15 ----
-    const int n0 = col0 + wn * 64 + 16 * lg;
-    float bias[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bias[j] = 0.f;
-    if (a.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 b = *(const float4*)(a.bias + n0 + 4 * j);
-            bias[4 * j] = b.x; bias[4 * j + 1] = b.y; bias[4 * j + 2] = b.z; bias[4 * j + 3] = b.w;
-        }
+    {
+        __syncthreads();
+        const char* base = smem + ((nk - 1) & 1) * STAGE;
+        bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+        load_frags(base, 0, xf0, wf0);
+        load_frags(base, 1, xf1, wf1);
+        mma(xf0, wf0);
+        mma(xf1, wf1);
     }
+    // ---- epilogue: accumulator register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column
+    // 4*li + nt of the wave's slab: per (mt, r) a lane owns 4 contiguous columns
+    const int n0 = col0 + wn * 64 + 4 * li;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias = *(const float4*)(a.bias + n0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = row0 + wm * WM + mt * 16 + li;
-        if (m >= M) continue;
-        float v[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r] + bias[4 * nt + r];
-
-        if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
-            size_t orow = m;
-            if constexpr (EPI == EPI_PATCH) {
-                int img = m / a.G2, p = m - img * a.G2;
-                orow = (size_t)img * a.T + 1 + p;
-                const float* pp = a.pos + (size_t)(1 + p) * a.N + n0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 t = *(const float4*)(pp + 4 * j);
-                    v[4 * j] += t.x; v[4 * j + 1] += t.y; v[4 * j + 2] += t.z; v[4 * j + 3] += t.w;
+        for (int r = 0; r < 4; ++r) {
+            const int m = row0 + wm * WM + mt * 16 + 4 * lg + r;
+            if (m >= M) continue;
+            float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
+            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
+                size_t orow = m;
+                if constexpr (EPI == EPI_PATCH) {
+                    int img = m / a.G2, p = m - img * a.G2;
+                    orow = (size_t)img * a.T + 1 + p;
+                    float4 t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
+                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
-            }
-            if constexpr (EPI == EPI_RESID_F32) {
-                const float* rp = a.resid + (size_t)m * a.ldr + n0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 t = *(const float4*)(rp + 4 * j);
-                    v[4 * j] += t.x; v[4 * j + 1] += t.y; v[4 * j + 2] += t.z; v[4 * j + 3] += t.w;
+                if constexpr (EPI == EPI_RESID_F32) {
+                    float4 t = *(const float4*)(a.resid + (size_t)m * a.ldr + n0);
+                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
-            }
-            float* cp = (float*)a.C + orow * a.ldc + n0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *(float4*)(cp + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-        } else {
-            if constexpr (EPI == EPI_GELU) {
-                if (a.C2) {
-                    bf16_t* up = a.C2 + (size_t)m * a.ldc2 + n0;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        *(u32x4*)(up + 8 * j) = u32x4{pack_bf16x2(v[8 * j], v[8 * j + 1]), pack_bf16x2(v[8 * j + 2], v[8 * j + 3]),
-                                                      pack_bf16x2(v[8 * j + 4], v[8 * j + 5]), pack_bf16x2(v[8 * j + 6], v[8 * j + 7])};
+                *(float4*)((float*)a.C + orow * a.ldc + n0) = make_float4(v0, v1, v2, v3);
+            } else {
+                if constexpr (EPI == EPI_GELU) {
+                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = quick_gelu_f(v[j]);
-            }
-            if constexpr (EPI == EPI_GELU_BWD) {
-                const bf16_t* up = a.aux + (size_t)m * a.ldaux + n0;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    u32x4 t = *(const u32x4*)(up + 8 * j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[8 * j + 2 * e] *= quick_gelu_grad_f(bf16lo(t[e]));
-                        v[8 * j + 2 * e + 1] *= quick_gelu_grad_f(bf16hi(t[e]));
-                    }
+                if constexpr (EPI == EPI_GELU_BWD) {
+                    u32x2 t = *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
+                    v0 *= quick_gelu_grad_f(bf16lo(t[0])); v1 *= quick_gelu_grad_f(bf16hi(t[0]));
+                    v2 *= quick_gelu_grad_f(bf16lo(t[1])); v3 *= quick_gelu_grad_f(bf16hi(t[1]));
                 }
+                *(u32x2*)((bf16_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
             }
-            bf16_t* cp = (bf16_t*)a.C + (size_t)m * a.ldc + n0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                *(u32x4*)(cp + 8 * j) = u32x4{pack_bf16x2(v[8 * j], v[8 * j + 1]), pack_bf16x2(v[8 * j + 2], v[8 * j + 3]),
-                                              pack_bf16x2(v[8 * j + 4], v[8 * j + 5]), pack_bf16x2(v[8 * j + 6], v[8 * j + 7])};
         }
     }
 }
 
-template <int BM, int EPI>
+template <int BM, int WMW, int WNW, int EPI>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+    constexpr int BN = 64 * WNW;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    hipLaunchKernelGGL((gemm_kernel<BM, EPI>), dim3(ntm * ntn), dim3(256), SMEM, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, EPI>), dim3(ntm * ntn), dim3(64 * WMW * WNW), SMEM, s, a);
     return hipGetLastError();
+}
+
+// Tile choice (measured in situ, tools/quick_bench.py): 160x128 with two blocks per CU.  M = 12608
+// gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 / 2.78 / 3.70
+// rounds of the 512 resident slots (>= 93% of whole rounds, vs 77% for 128x128 at N = 768), and the
+// second resident block covers the first one's prologue DMA latency and store tail.  320x128 with 8
+// waves (one block per CU) has the same quantisation and less L2->LDS traffic but nothing to overlap
+// its per-tile prologue/epilogue with at K = 768.  Small-M calls (1-view inference) use 128x128.
+template <int EPI>
+hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
+    static int variant = -1;
+    if (variant < 0) { const char* v = getenv("TTL_GEMM_VARIANT"); variant = v ? atoi(v) : 2; }
+    if (a.M < 1024 || variant == 0) return launch_t<128, 2, 2, EPI>(a, s);
+    if (variant == 2) return launch_t<160, 2, 2, EPI>(a, s);
+    return launch_t<320, 4, 2, EPI>(a, s);
 }
 
 }  // namespace
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N % BN || a.K % BK || a.K <= 0 || (a.lda & 7) || (a.ldb & 7)) return hipErrorInvalidValue;
+    if (a.M <= 0 || a.N % 128 || a.K % BK || a.K <= 0 || (a.lda & 7) || (a.ldb & 7)) return hipErrorInvalidValue;
     switch (epi) {
-        case EPI_F32: return launch_t<128, EPI_F32>(a, s);
-        case EPI_BF16: return launch_t<128, EPI_BF16>(a, s);
-        case EPI_RESID_F32: return launch_t<128, EPI_RESID_F32>(a, s);
-        case EPI_GELU: return launch_t<128, EPI_GELU>(a, s);
-        case EPI_PATCH: return launch_t<128, EPI_PATCH>(a, s);
-        case EPI_GELU_BWD: return launch_t<128, EPI_GELU_BWD>(a, s);
+        case EPI_F32: return launch_v<EPI_F32>(a, s);
+        case EPI_BF16: return launch_v<EPI_BF16>(a, s);
+        case EPI_RESID_F32: return launch_v<EPI_RESID_F32>(a, s);
+        case EPI_GELU: return launch_v<EPI_GELU>(a, s);
+        case EPI_PATCH: return launch_v<EPI_PATCH>(a, s);
+        case EPI_GELU_BWD: return launch_v<EPI_GELU_BWD>(a, s);
     }
     return hipErrorInvalidValue;
 }

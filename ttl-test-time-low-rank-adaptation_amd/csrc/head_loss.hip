@@ -39,8 +39,19 @@ __global__ __launch_bounds__(HB) void head_proj_kernel(HeadArgs a) {
     for (int d = threadIdx.x; d < a.D; d += HB) sm[d] = a.y[(size_t)v * a.D + d];
     __syncthreads();
     if (e >= a.E) return;
-    float acc = 0.f;
-    for (int d = 0; d < a.D; ++d) acc = fmaf(sm[d], a.WpT[(size_t)d * a.E + e], acc);
+    // 4 independent chains x unroll: keeps ~16 loads in flight per thread (latency-bound otherwise)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* w = a.WpT + e;
+    int d = 0;
+#pragma unroll 4
+    for (; d + 4 <= a.D; d += 4) {
+        a0 = fmaf(sm[d], w[(size_t)d * a.E], a0);
+        a1 = fmaf(sm[d + 1], w[(size_t)(d + 1) * a.E], a1);
+        a2 = fmaf(sm[d + 2], w[(size_t)(d + 2) * a.E], a2);
+        a3 = fmaf(sm[d + 3], w[(size_t)(d + 3) * a.E], a3);
+    }
+    for (; d < a.D; ++d) a0 = fmaf(sm[d], w[(size_t)d * a.E], a0);
+    const float acc = (a0 + a1) + (a2 + a3);
     a.f[(size_t)v * a.E + e] = acc;
     if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
 }
@@ -53,9 +64,18 @@ __global__ __launch_bounds__(HB) void head_logits_kernel(HeadArgs a) {
     for (int e = threadIdx.x; e < a.E; e += HB) { float t = a.f[(size_t)v * a.E + e]; sm[e] = t; nn += t * t; }
     const float inv = a.scale / sqrtf(block_sum(nn, red));
     if (k >= a.K) return;
-    float acc = 0.f;
-    for (int e = 0; e < a.E; ++e) acc = fmaf(sm[e], a.tfeatT[(size_t)e * a.K + k], acc);
-    a.logits[(size_t)v * a.K + k] = acc * inv;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* w = a.tfeatT + k;
+    int e = 0;
+#pragma unroll 4
+    for (; e + 4 <= a.E; e += 4) {
+        a0 = fmaf(sm[e], w[(size_t)e * a.K], a0);
+        a1 = fmaf(sm[e + 1], w[(size_t)(e + 1) * a.K], a1);
+        a2 = fmaf(sm[e + 2], w[(size_t)(e + 2) * a.K], a2);
+        a3 = fmaf(sm[e + 3], w[(size_t)(e + 3) * a.K], a3);
+    }
+    for (; e < a.E; ++e) a0 = fmaf(sm[e], w[(size_t)e * a.K], a0);
+    a.logits[(size_t)v * a.K + k] = ((a0 + a1) + (a2 + a3)) * inv;
 }
 // ---- head backward
 // grid (ceil(E/HB), n): dfh[v][e] = scale * sum_k dz[v][k] t[k][e]
@@ -65,9 +85,18 @@ __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* _
     for (int k = threadIdx.x; k < a.K; k += HB) sm[k] = dz[(size_t)v * a.K + k];
     __syncthreads();
     if (e >= a.E) return;
-    float acc = 0.f;
-    for (int k = 0; k < a.K; ++k) acc = fmaf(sm[k], a.tfeat[(size_t)k * a.E + e], acc);
-    a.tmp_e[(size_t)v * a.E + e] = acc * a.scale;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* w = a.tfeat + e;
+    int k = 0;
+#pragma unroll 4
+    for (; k + 4 <= a.K; k += 4) {
+        a0 = fmaf(sm[k], w[(size_t)k * a.E], a0);
+        a1 = fmaf(sm[k + 1], w[(size_t)(k + 1) * a.E], a1);
+        a2 = fmaf(sm[k + 2], w[(size_t)(k + 2) * a.E], a2);
+        a3 = fmaf(sm[k + 3], w[(size_t)(k + 3) * a.E], a3);
+    }
+    for (; k < a.K; ++k) a0 = fmaf(sm[k], w[(size_t)k * a.E], a0);
+    a.tmp_e[(size_t)v * a.E + e] = ((a0 + a1) + (a2 + a3)) * a.scale;
 }
 // grid (ceil(D/HB), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
 __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
@@ -85,9 +114,18 @@ __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
     for (int e = threadIdx.x; e < a.E; e += HB) sm[e] = (dfh[e] - (f[e] / nrm) * dot) / nrm;
     __syncthreads();
     if (d >= a.D) return;
-    float acc = 0.f;
-    for (int e = 0; e < a.E; ++e) acc = fmaf(sm[e], a.Wp[(size_t)e * a.D + d], acc);
-    a.tmp_d[(size_t)v * a.D + d] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* w = a.Wp + d;
+    int e = 0;
+#pragma unroll 4
+    for (; e + 4 <= a.E; e += 4) {
+        a0 = fmaf(sm[e], w[(size_t)e * a.D], a0);
+        a1 = fmaf(sm[e + 1], w[(size_t)(e + 1) * a.D], a1);
+        a2 = fmaf(sm[e + 2], w[(size_t)(e + 2) * a.D], a2);
+        a3 = fmaf(sm[e + 3], w[(size_t)(e + 3) * a.D], a3);
+    }
+    for (; e < a.E; ++e) a0 = fmaf(sm[e], w[(size_t)e * a.D], a0);
+    a.tmp_d[(size_t)v * a.D + d] = (a0 + a1) + (a2 + a3);
 }
 
 // ---- loss, pass 1: one block per view: row softmax statistics -> H_i, lse_i
