@@ -152,7 +152,7 @@ void set_geometry(ttl_ctx* c, const ttl_config* k) {
     c->ldw = c->D + 64;        // wqkv rows
     c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
     c->nT = k->layer_hi - k->layer_lo + 1;
-    c->Mmax = k->max_views * c->T;
+    c->Mmax = round_up(k->max_views * c->T, 320);  // padded: the big GEMM tiles store whole row tiles unguarded
     c->scaling = k->lora_alpha / (float)k->rank;
 }
 
@@ -167,8 +167,10 @@ struct Prof {
     }
 };
 
-int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a, hipStream_t s) {
+int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     Prof p(c, 0, s);
+    GemmArgs a = a0;
+    a.padded = 1;   // every arena buffer has Mmax = round_up(N*T, 320) rows
     if (c->prof) c->gemm_flops += 2.0 * a.M * a.N * a.K;
     HIP_TRY(launch_gemm(epi, a, s));
     return 0;

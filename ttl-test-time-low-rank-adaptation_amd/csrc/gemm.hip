@@ -3,7 +3,8 @@
 // Replaces the nn.Linear / Conv2d matmuls the reference runs through torch (HF
 // modeling_clip.py:202-218 patch conv, :309-311 q/k/v, :333 out_proj, :346-350 fc1/fc2) and
 // their autograd dgrad counterparts.  gfx950 design:
-//   * block tile BM x 128 x 64, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, fp32 accumulate
+//   * block tile 160 x 128 x 64 (128 x 128 for small M), 4 waves (2x2), two blocks per CU,
+//     v_mfma_f32_16x16x32_bf16, fp32 accumulate
 //   * operands staged HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
 //     stages, next tile's DMA in flight under the current tile's MFMAs
 //   * LDS image is lane-linear (DMA constraint), bank conflicts removed by XOR-swizzling the
@@ -35,9 +36,55 @@ struct SchedLoop<NP, NP, NP0, MPER, DPER> {
     static __device__ __forceinline__ void run() {}
 };
 
+// ---- epilogue shared by both kernels: accumulator register r of sub-tile (mt, nt) is row
+// 16*mt + 4*lg + r, column 4*li + nt of the wave's 64-column slab: per (mt, r) a lane owns 4
+// contiguous columns, so one store instruction writes 4 rows x 256 B (fp32) / 128 B (bf16).
+// GUARD = false: the caller guarantees that every row of the last row tile exists in all output /
+// residual / aux buffers (the context pads its arena), so the epilogue is straight-line code: with
+// a per-row branch hipcc re-waits vmcnt(0) in every store block and the stores serialise.
+template <int EPI, int MT, bool GUARD>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg, int M) {
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias = *(const float4*)(a.bias + n0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = rbase + mt * 16 + 4 * lg + r;
+            if (GUARD && m >= M) continue;
+            float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
+            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
+                size_t orow = m;
+                if constexpr (EPI == EPI_PATCH) {
+                    int img = m / a.G2, p = m - img * a.G2;
+                    orow = (size_t)img * a.T + 1 + p;
+                    float4 t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
+                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
+                }
+                if constexpr (EPI == EPI_RESID_F32) {
+                    float4 t = *(const float4*)(a.resid + (size_t)m * a.ldr + n0);
+                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
+                }
+                *(float4*)((float*)a.C + orow * a.ldc + n0) = make_float4(v0, v1, v2, v3);
+            } else {
+                if constexpr (EPI == EPI_GELU) {
+                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
+                }
+                if constexpr (EPI == EPI_GELU_BWD) {
+                    u32x2 t = *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
+                    v0 *= quick_gelu_grad_f(bf16lo(t[0])); v1 *= quick_gelu_grad_f(bf16hi(t[0]));
+                    v2 *= quick_gelu_grad_f(bf16lo(t[1])); v3 *= quick_gelu_grad_f(bf16hi(t[1]));
+                }
+                *(u32x2*)((bf16_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            }
+        }
+    }
+}
+
 // BM x (64*WNW) block tile, WMW x WNW waves, every wave owns (BM/WMW) x 64 outputs.
-template <int BM, int WMW, int WNW, int EPI>
-__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW >= 8) ? 2 : 2) void gemm_kernel(const GemmArgs a) {
+template <int BM, int WMW, int WNW, int EPI, bool GUARD>
+__global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WMW * WNW;
     constexpr int BN = 64 * WNW;
@@ -158,77 +205,47 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW >= 8) ? 2 : 2) void gemm
         mma(xf0, wf0);
         mma(xf1, wf1);
     }
-    // ---- epilogue: accumulator register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column
-    // 4*li + nt of the wave's slab: per (mt, r) a lane owns 4 contiguous columns
-    const int n0 = col0 + wn * 64 + 4 * li;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bias = *(const float4*)(a.bias + n0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = row0 + wm * WM + mt * 16 + 4 * lg + r;
-            if (m >= M) continue;
-            float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
-            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
-                size_t orow = m;
-                if constexpr (EPI == EPI_PATCH) {
-                    int img = m / a.G2, p = m - img * a.G2;
-                    orow = (size_t)img * a.T + 1 + p;
-                    float4 t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
-                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
-                }
-                if constexpr (EPI == EPI_RESID_F32) {
-                    float4 t = *(const float4*)(a.resid + (size_t)m * a.ldr + n0);
-                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
-                }
-                *(float4*)((float*)a.C + orow * a.ldc + n0) = make_float4(v0, v1, v2, v3);
-            } else {
-                if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                    v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
-                }
-                if constexpr (EPI == EPI_GELU_BWD) {
-                    u32x2 t = *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
-                    v0 *= quick_gelu_grad_f(bf16lo(t[0])); v1 *= quick_gelu_grad_f(bf16hi(t[0]));
-                    v2 *= quick_gelu_grad_f(bf16lo(t[1])); v3 *= quick_gelu_grad_f(bf16hi(t[1]));
-                }
-                *(u32x2*)((bf16_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-            }
-        }
-    }
+    gemm_epilogue<EPI, MT, GUARD>(a, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
 }
 
-template <int BM, int WMW, int WNW, int EPI>
+template <int BM, int WMW, int WNW, int EPI, bool GUARD = true>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BN = 64 * WNW;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, EPI, GUARD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, EPI>), dim3(ntm * ntn), dim3(64 * WMW * WNW), SMEM, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, EPI, GUARD>), dim3(ntm * ntn), dim3(64 * WMW * WNW), SMEM, s, a);
     return hipGetLastError();
 }
 
-// Tile choice (measured in situ, tools/quick_bench.py): 160x128 with two blocks per CU.  M = 12608
-// gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 / 2.78 / 3.70
-// rounds of the 512 resident slots (>= 93% of whole rounds, vs 77% for 128x128 at N = 768), and the
-// second resident block covers the first one's prologue DMA latency and store tail.  320x128 with 8
-// waves (one block per CU) has the same quantisation and less L2->LDS traffic but nothing to overlap
-// its per-tile prologue/epilogue with at K = 768.  Small-M calls (1-view inference) use 128x128.
+// Tile choice (measured in situ on the 64-view ViT-B/16 episode, tools/quick_bench.py):
+//   160x128x64, 4 waves, 2 blocks/CU, unguarded epilogue ........ 3.85 ms of GEMM per image  <- used
+//   same with the per-row guard in the epilogue .................. 4.21 ms (hipcc re-waits vmcnt(0) per store block)
+//   320x128x64, 8 waves, 1 block/CU .............................. 4.35 ms (nothing overlaps its prologue/epilogue)
+//   160x128x32, 2/3/4-stage LDS ring, counted vmcnt, register
+//   double-buffered fragments, 2-3 blocks/CU ..................... 4.37-4.48 ms (twice the barriers per K)
+// M = 12608 gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 /
+// 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
+// The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
+// 64-71 FLOP per staged byte is near the L2->LDS ceiling: the next step is a larger block tile.
+// Small-M calls (1-view inference) use 128x128 with the guarded epilogue.
 template <int EPI>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
     static int variant = -1;
     if (variant < 0) { const char* v = getenv("TTL_GEMM_VARIANT"); variant = v ? atoi(v) : 2; }
     if (a.M < 1024 || variant == 0) return launch_t<128, 2, 2, EPI>(a, s);
-    if (variant == 2) return launch_t<160, 2, 2, EPI>(a, s);
-    return launch_t<320, 4, 2, EPI>(a, s);
+    if (a.padded && EPI != EPI_PATCH) {
+        if (variant == 1) return launch_t<320, 4, 2, EPI, false>(a, s);
+        return launch_t<160, 2, 2, EPI, false>(a, s);
+    }
+    return launch_t<160, 2, 2, EPI, true>(a, s);
 }
 
 }  // namespace

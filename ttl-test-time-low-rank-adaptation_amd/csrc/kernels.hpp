@@ -24,6 +24,7 @@ struct GemmArgs {
     bf16_t* C2; int ldc2;         // EPI_GELU second output (pre-activation), may be null
     const bf16_t* aux; int ldaux; // EPI_GELU_BWD: saved pre-activation u
     const float* pos; int G2; int T; // EPI_PATCH
+    int padded;                   // all C/resid/aux/C2 buffers have rows up to round_up(M, 320): unguarded epilogue allowed
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
