@@ -94,6 +94,8 @@ struct ttl_ctx {
     float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits, *head_te, *head_td;
     // backward scratch
     float *dh, *dh2, *dx; bf16_t *dh16, *dbig, *dattn, *dqkv;
+    // top-layer backward works on the CLS rows only (compact [N, .] buffers)
+    float *dcls, *dxc, *dhmc; bf16_t *dcls16, *dgc, *dhmc16, *doc;
     float* wg_partial;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
     bool saved = false; int saved_n = 0; int stream_views = 0;
@@ -245,6 +247,8 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->dh, M * D, false); ALLOC(c->dh2, M * D, false); ALLOC(c->dx, M * D, false);
     ALLOC(c->dh16, M * D, false); ALLOC(c->dbig, M * F, false); ALLOC(c->dattn, M * D, false);
     ALLOC(c->dqkv, M * c->ldwt, true);
+    ALLOC(c->dcls, N * D, false); ALLOC(c->dxc, N * D, false); ALLOC(c->dhmc, N * D, false);
+    ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * D, false); ALLOC(c->doc, N * D, false);
     ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 4 * r * D, false);
     ALLOC(c->loss_scratch, 4 * N + 3 * (size_t)k->max_classes + 16, true);
     ALLOC(c->idx_buf, N, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, N, true);
@@ -569,44 +573,78 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
     float* dh_alt = c->dh2;
     {
         Prof p(c, 5, s);
-        HIP_TRY(launch_fill_zero(dh, (size_t)M * D * sizeof(float), s));
-        HIP_TRY(launch_fill_zero(c->dh16, (size_t)M * D * sizeof(bf16_t), s));
         HeadArgs a = head_args(c, c->h_out[c->nT - 1], nullptr, c->logits);
-        HIP_TRY(launch_head_bwd(a, dlogits, dh, c->dh16, n, s));
+        HIP_TRY(launch_head_bwd(a, dlogits, c->dcls, c->dcls16, n, s));
     }
     const size_t per = (size_t)r * D;
+    const float* dres_cls = nullptr;   // != null: d/d h_mid of the layer above is compact (CLS rows only)
     for (int i = c->c.layer_hi; i >= c->c.layer_lo; --i) {
         Layer& l = c->layers[i];
         const bool first = (i == c->c.layer_lo);
-        // ---- MLP: dg = dh·W2 (∘ gelu'(u)) ; dx2 = du·W1 ; dh_mid = dh + LN2^T(dx2)
-        {
-            GemmArgs a = {};
-            a.A = c->dh16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = M; a.N = F; a.K = D;
-            a.C = c->dbig; a.ldc = F; a.aux = l.u; a.ldaux = F;
-            if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
+        if (i == c->c.layer_hi) {
+            // ---- top layer: the loss reads the CLS token only, so d/d h_out is non-zero on the n CLS
+            // rows: MLP, LN2 and out_proj backward run on a compact [n, .] problem (row pitch T*D / T*F
+            // picks the CLS rows of the saved activations) and attention backward is rank-1 per head.
+            {
+                GemmArgs a = {};
+                a.A = c->dcls16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = n; a.N = F; a.K = D;
+                a.C = c->dgc; a.ldc = F; a.aux = l.u; a.ldaux = T * F;
+                if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
+            }
+            {
+                GemmArgs a = {};
+                a.A = c->dgc; a.lda = F; a.B = l.w1T; a.ldb = F; a.M = n; a.N = D; a.K = F;
+                a.C = c->dxc; a.ldc = D;
+                if ((rc = gemm(c, EPI_F32, a, s))) return rc;
+            }
+            {
+                Prof p(c, 3, s);
+                HIP_TRY(launch_layernorm_bwd(c->dxc, l.h_mid, l.mu2, l.rs2, l.ln2g, c->dcls, c->dhmc, c->dhmc16, n, D, s,
+                                             (long long)T * D, (long long)D, T, 0));
+            }
+            {
+                GemmArgs a = {};
+                a.A = c->dhmc16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = n; a.N = D; a.K = D;
+                a.C = c->doc; a.ldc = D;
+                if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+            }
+            {
+                Prof p(c, 2, s);
+                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, D, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
+            }
+            dres_cls = c->dhmc;
+        } else {
+            // ---- MLP: dg = dh·W2 (∘ gelu'(u)) ; dx2 = du·W1 ; dh_mid = dh + LN2^T(dx2)
+            {
+                GemmArgs a = {};
+                a.A = c->dh16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = M; a.N = F; a.K = D;
+                a.C = c->dbig; a.ldc = F; a.aux = l.u; a.ldaux = F;
+                if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
+            }
+            {
+                GemmArgs a = {};
+                a.A = c->dbig; a.lda = F; a.B = l.w1T; a.ldb = F; a.M = M; a.N = D; a.K = F;
+                a.C = c->dx; a.ldc = D;
+                if ((rc = gemm(c, EPI_F32, a, s))) return rc;
+            }
+            {
+                Prof p(c, 3, s);
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_mid, l.mu2, l.rs2, l.ln2g, dh, dh_alt, c->dh16, M, D, s));
+            }
+            // ---- attention output projection: do = dh_mid·Wo
+            {
+                GemmArgs a = {};
+                a.A = c->dh16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = M; a.N = D; a.K = D;
+                a.C = c->dattn; a.ldc = D;
+                if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+            }
+            {
+                Prof p(c, 2, s);
+                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
+            }
+            dres_cls = nullptr;
         }
-        {
-            GemmArgs a = {};
-            a.A = c->dbig; a.lda = F; a.B = l.w1T; a.ldb = F; a.M = M; a.N = D; a.K = F;
-            a.C = c->dx; a.ldc = D;
-            if ((rc = gemm(c, EPI_F32, a, s))) return rc;
-        }
-        {
-            Prof p(c, 3, s);
-            HIP_TRY(launch_layernorm_bwd(c->dx, l.h_mid, l.mu2, l.rs2, l.ln2g, dh, dh_alt, c->dh16, M, D, s));
-        }
-        float* dhm = dh_alt;  // d/d h_mid
-        // ---- attention output projection: do = dh_mid·Wo
-        {
-            GemmArgs a = {};
-            a.A = c->dh16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = M; a.N = D; a.K = D;
-            a.C = c->dattn; a.ldc = D;
-            if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
-        }
-        {
-            Prof p(c, 2, s);
-            HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
-        }
+        float* dhm = dh_alt;  // d/d h_mid (dense layers)
         // ---- LoRA: dU = s·[dq·B_q | dv·B_v] ; dA, dB
         {
             Prof p(c, 4, s);
@@ -624,7 +662,10 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
         }
         {
             Prof p(c, 3, s);
-            HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s));
+            if (dres_cls)
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dres_cls, dh, c->dh16, M, D, s, 0, 0, 1, T));
+            else
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s));
         }
         // dh now holds d/d h_in of layer i == d/d h_out of layer i-1
     }

@@ -303,6 +303,77 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------ backward, CLS query only
+// Top layer: the loss reads only the CLS token, so d(out) is non-zero for query 0 alone and the
+// whole backward of a (view, head) collapses to rank-1 work (SURVEY appendix A with q = q_0):
+//   p_j = exp(q0.k_j/8 - lse0), dp_j = do0.v_j, ds_j = p_j (dp_j - do0.o0),
+//   dq_0 = sum_j ds_j k_j / 8,  dk_j = ds_j q0 / 8,  dv_j = p_j do0;   dq_t = 0 for t > 0.
+template <bool NEED_DK>
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out,
+                                                           int ldo, const bf16_t* __restrict__ dout_cls,
+                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int ldd,
+                                                           int T, int H) {
+    __shared__ float sq[64], sdo[64], sds[320], sred[4][64];
+    __shared__ float sdelta;
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const bf16_t* base = qkv + (size_t)img * T * ld + head * 64;
+    if (tid < 64) {
+        sq[tid] = bf16_to_f32(base[tid]);
+        float d = bf16_to_f32(dout_cls[(size_t)img * D + head * 64 + tid]);
+        sdo[tid] = d;
+        float prod = d * bf16_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]);
+        prod = wave_sum(prod);
+        if (tid == 0) sdelta = prod;
+    }
+    __syncthreads();
+    const float l0 = lse[((size_t)img * H + head) * T];
+    const float delta = sdelta;
+    for (int j = tid; j < T; j += 256) {
+        const bf16_t* kr = base + (size_t)j * ld + D;
+        const bf16_t* vr = base + (size_t)j * ld + 2 * D;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            bf16x8 kf = *(const bf16x8*)(kr + 8 * c), vf = *(const bf16x8*)(vr + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s = fmaf(sq[8 * c + e], (float)kf[e], s); dp = fmaf(sdo[8 * c + e], (float)vf[e], dp); }
+        }
+        const float p = __expf(s * SCALE - l0);
+        // the MFMA path rounds P and dS to bf16 before the second products; keep the same points
+        const float pb = bf16_to_f32(f32_to_bf16(p));
+        const float ds = bf16_to_f32(f32_to_bf16(p * (dp - delta)));
+        sds[j] = ds;
+        bf16_t* o = dqkv + (size_t)(img * T + j) * ldd + head * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u32x4 dv, dk, z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dv[e] = pack_bf16x2(pb * sdo[8 * c + 2 * e], pb * sdo[8 * c + 2 * e + 1]);
+                dk[e] = pack_bf16x2(ds * sq[8 * c + 2 * e] * SCALE, ds * sq[8 * c + 2 * e + 1] * SCALE);
+            }
+            *(u32x4*)(o + 2 * D + 8 * c) = dv;
+            if (NEED_DK) *(u32x4*)(o + D + 8 * c) = dk;
+            if (j > 0) *(u32x4*)(o + 8 * c) = z;
+        }
+    }
+    __syncthreads();
+    // dq_0[d] = sum_j ds_j k_j[d] / 8 : 4 waves split the keys, lane = d
+    {
+        const int d = tid & 63, w = tid >> 6;
+        float acc = 0.f;
+        for (int j = w; j < T; j += 4) acc = fmaf(sds[j], bf16_to_f32(base[(size_t)j * ld + D + d]), acc);
+        sred[w][d] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+        dqkv[(size_t)(img * T) * ldd + head * 64 + tid] = f32_to_bf16(v * SCALE);
+    }
+}
+
 template <typename K>
 hipError_t set_smem(K kernel, int bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -364,4 +435,17 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out
     if (nkt <= 7) return bwd_t<7>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
     if (nkt <= 9) return bwd_t<9>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_attention_bwd_cls(const bf16_t* qkv, int ld_qkv, const bf16_t* out, int ld_o, const bf16_t* dout_cls,
+                                    const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+                                    hipStream_t s) {
+    if (T > 320) return hipErrorInvalidValue;
+    if (need_dk)
+        hipLaunchKernelGGL((attn_bwd_cls_kernel<true>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
+                           ld_dqkv, T, H);
+    else
+        hipLaunchKernelGGL((attn_bwd_cls_kernel<false>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
+                           ld_dqkv, T, H);
+    return hipGetLastError();
 }

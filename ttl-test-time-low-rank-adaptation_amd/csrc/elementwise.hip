@@ -136,12 +136,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ o32, bf16_t* __restrict__ o16, int rows, int D,
-                                                     long long xs, long long os) {
+                                                     long long xs, long long os, int stat_stride, int dres_T) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
     const int nch = D >> 2;
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = mean[(size_t)row * stat_stride], rs = rstd[(size_t)row * stat_stride];
+    // dres_T > 0: the residual gradient is non-zero only on rows that are multiples of dres_T
+    // (the CLS tokens) and is stored compactly as [rows / dres_T][D]
+    const float* dres_row = nullptr;
+    if (dres) {
+        if (dres_T > 0) { if (row % dres_T == 0) dres_row = dres + (size_t)(row / dres_T) * D; }
+        else dres_row = dres + (size_t)row * os;
+    }
     float4 dxh[LN_MAXC], xh[LN_MAXC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < LN_MAXC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
-            float4 r = dres ? *(const float4*)(dres + (size_t)row * os + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 r = dres_row ? *(const float4*)(dres_row + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
@@ -216,10 +223,12 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16, int rows,
-                                int D, hipStream_t s, long long x_stride, long long o_stride) {
+                                int D, hipStream_t s, long long x_stride, long long o_stride, int stat_stride,
+                                int dres_T) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
-                       out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D);
+                       out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D,
+                       stat_stride, dres_T);
     return hipGetLastError();
 }
 

@@ -324,9 +324,9 @@ hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, b
     hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // LayerNorm backward on the CLS rows, written straight into the (pre-zeroed) stream gradient
+    // LayerNorm backward on the CLS rows -> compact [n, D]
     return launch_layernorm_bwd(a.tmp_d, a.h, a.cls_mean, a.cls_rstd, a.ln_g, nullptr, dh, dh16, n, a.D, s,
-                                (long long)a.T * a.D, (long long)a.T * a.D);
+                                (long long)a.T * a.D, (long long)a.D);
 }
 
 // scratch layout (floats): [0,N) lse | [N,2N) coef | [2N,2N+1) nsel(int) | [2N+4, 2N+4+N) H (if H_out null)

@@ -47,10 +47,13 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
                             float* y_f32, bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
                             int D, float eps, hipStream_t s);
 // dx = LN-backward(dy; x, mean, rstd, gamma); out_f32 = dres + dx; out_bf16 = bf16(out_f32)
-// x_stride / o_stride: row pitch (elements) of x and of the outputs (D when contiguous)
+// x_stride / o_stride: row pitch (elements) of x and of dres/outputs (D when contiguous);
+// stat_stride: pitch of mean/rstd; dres_T > 0: dres is compact [rows/dres_T][D], non-zero only on
+// rows that are multiples of dres_T (CLS tokens)
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16,
-                                int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0);
+                                int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0,
+                                int stat_stride = 1, int dres_T = 0);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
@@ -59,6 +62,11 @@ hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int 
 hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out, const bf16_t* dout, int ld_o,
                                 const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s);
+// Same gradients when d(out) is non-zero only for the CLS query of every view (the top layer):
+// dout_cls bf16 [n][H*64]; writes dense dq (zero rows for tokens > 0), dk, dv.
+hipError_t launch_attention_bwd_cls(const bf16_t* qkv, int ld_qkv, const bf16_t* out, int ld_o, const bf16_t* dout_cls,
+                                    const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+                                    hipStream_t s);
 
 // ---------------------------------------------------------------- head / loss / optimizer (head_loss.hip)
 struct HeadArgs {
@@ -75,8 +83,9 @@ struct HeadArgs {
     float* tmp_e; float* tmp_d;  // scratch [n,E], [n,D] (backward)
 };
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s);
-// dlogits [n,K] -> dh rows n*T (CLS) fp32 + bf16 copy; other rows are NOT touched
-hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, bf16_t* dh_bf16, int n, hipStream_t s);
+// dlogits [n,K] -> gradient of the CLS rows, compact [n,D] fp32 + bf16 copy (all other rows of
+// the stream gradient are zero)
+hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls, bf16_t* dcls_bf16, int n, hipStream_t s);
 
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
                                float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io,
