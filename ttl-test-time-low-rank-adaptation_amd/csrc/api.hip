@@ -97,6 +97,7 @@ struct ttl_ctx {
     // top-layer backward works on the CLS rows only (compact [N, .] buffers)
     float *dcls, *dxc, *dhmc; bf16_t *dcls16, *dgc, *dhmc16, *doc;
     float* wg_partial;
+    float* gemm_ws; size_t gemm_ws_bytes;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
     bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
@@ -173,6 +174,7 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     Prof p(c, 0, s);
     GemmArgs a = a0;
     a.padded = 1;   // every arena buffer has Mmax = round_up(N*T, 320) rows
+    a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
     if (c->prof) c->gemm_flops += 2.0 * a.M * a.N * a.K;
     HIP_TRY(launch_gemm(epi, a, s));
     return 0;
@@ -250,6 +252,8 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->dcls, N * D, false); ALLOC(c->dxc, N * D, false); ALLOC(c->dhmc, N * D, false);
     ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * D, false); ALLOC(c->doc, N * D, false);
     ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 4 * r * D, false);
+    c->gemm_ws_bytes = (size_t)8 << 20;
+    ALLOC(c->gemm_ws, c->gemm_ws_bytes / sizeof(float), false);
     ALLOC(c->loss_scratch, 4 * N + 3 * (size_t)k->max_classes + 16, true);
     ALLOC(c->idx_buf, N, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, N, true);
     guard.ok = true;

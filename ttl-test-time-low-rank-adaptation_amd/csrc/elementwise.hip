@@ -178,7 +178,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ resid,
+                                     int ldr, const float* __restrict__ bias, float* __restrict__ out, int ldc) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (size_t)M * N) return;
+    int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (resid) acc = *(const float4*)(resid + (size_t)m * ldr + n);
+    if (bias) { float4 b = *(const float4*)(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+    for (int s = 0; s < splits; ++s) {
+        float4 p = *(const float4*)(part + (size_t)s * M * N + i);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    *(float4*)(out + (size_t)m * ldc + n) = acc;
+}
+
 }  // namespace
+
+hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr, const float* bias,
+                                float* out, int ldc, hipStream_t s) {
+    size_t n4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, splits, M, N, resid, ldr,
+                       bias, out, ldc);
+    return hipGetLastError();
+}
 
 hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;

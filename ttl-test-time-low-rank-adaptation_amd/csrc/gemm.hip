@@ -83,7 +83,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
 }
 
 // BM x (64*WNW) block tile, WMW x WNW waves, every wave owns (BM/WMW) x 64 outputs.
-template <int BM, int WMW, int WNW, int EPI, bool GUARD>
+// STAGES == 2: one K-tile in flight, plain __syncthreads().  STAGES > 2 (small-M calls, which are
+// latency-bound: a dozen blocks on the whole chip): STAGES-1 tiles of DMA in flight behind a counted
+// s_waitcnt vmcnt(N) + raw s_barrier; tiles past the end re-load the last tile into a dead stage so
+// that ONE immediate serves the whole loop.
+template <int BM, int WMW, int WNW, int STAGES, int EPI, bool GUARD>
 __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WMW * WNW;
@@ -107,6 +111,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     const int row0 = (bid / ntn) * BM;
     const int col0 = (bid % ntn) * BN;
     const int M = a.M;
+    // split-K (small-M fp32 partials): slice blockIdx.y covers K/splits and writes its own [M][ldc] slab
+    const int nk = a.K / BK / a.splits;
+    const size_t koff = (size_t)blockIdx.y * nk * BK;
 
     // ---- per-thread DMA sources (row fixed for the whole K loop) ----
     const bf16_t* asrc[NA];
@@ -116,14 +123,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int gr = min(row0 + r, M - 1);
-        asrc[i] = a.A + (size_t)gr * a.lda + c * 8;
+        asrc[i] = a.A + (size_t)gr * a.lda + c * 8 + koff;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int n = (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);  // physical LDS row r holds this output column
-        bsrc[i] = a.B + (size_t)(col0 + n) * a.ldb + c * 8;
+        bsrc[i] = a.B + (size_t)(col0 + n) * a.ldb + c * 8 + koff;
     }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
@@ -151,7 +158,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.K / BK;
     constexpr int NP = NA + NB;            // DMA pieces per thread per K-tile
     constexpr int NP0 = (NP + 1) / 2;      // issued under the first 32-deep half, the rest under the second
     auto stage_piece = [&](int i, int kt, char* base) {
@@ -175,53 +181,75 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
     };
-    stage(0, 0);
-    // steady state: tile kt is consumed while tile kt+1's DMA is issued BETWEEN the MFMAs (the
-    // matrix pipe never waits behind a burst of DMA issue); the last tile is peeled (no prefetch)
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
-        const char* base = smem + (kt & 1) * STAGE;
-        char* nxt = smem + ((kt + 1) & 1) * STAGE;
-        bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
-        load_frags(base, 0, xf0, wf0);
-        load_frags(base, 1, xf1, wf1);
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
+        // steady state: tile kt is consumed while tile kt+1's DMA is issued BETWEEN the MFMAs (the
+        // matrix pipe never waits behind a burst of DMA issue); the last tile is peeled (no prefetch)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
+            const char* base = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            load_frags(base, 0, xf0, wf0);
+            load_frags(base, 1, xf1, wf1);
 #pragma unroll
-        for (int i = 0; i < NP0; ++i) stage_piece(i, kt + 1, nxt);
-        mma(xf0, wf0);
+            for (int i = 0; i < NP0; ++i) stage_piece(i, kt + 1, nxt);
+            mma(xf0, wf0);
 #pragma unroll
-        for (int i = NP0; i < NP; ++i) stage_piece(i, kt + 1, nxt);
-        mma(xf1, wf1);
-        // pin the interleave: fragments of the first half, then {MFMAs, one DMA piece, a few reads}
-        __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
-        SchedLoop<0, NP, NP0, (2 * MT * 4) / NP, (MT + 4 + NP0 - 1) / NP0>::run();
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * 4 - NP * ((2 * MT * 4) / NP), 0);
+            for (int i = NP0; i < NP; ++i) stage_piece(i, kt + 1, nxt);
+            mma(xf1, wf1);
+            // pin the interleave: fragments of the first half, then {MFMAs, one DMA piece, a few reads}
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
+            SchedLoop<0, NP, NP0, (2 * MT * 4) / NP, (MT + 4 + NP0 - 1) / NP0>::run();
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * 4 - NP * ((2 * MT * 4) / NP), 0);
+        }
+        {
+            __syncthreads();
+            const char* base = smem + ((nk - 1) & 1) * STAGE;
+            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            load_frags(base, 0, xf0, wf0);
+            load_frags(base, 1, xf1, wf1);
+            mma(xf0, wf0);
+            mma(xf1, wf1);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t) stage(min(t, nk - 1), t);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NP) : "memory");  // tile kt landed
+            __builtin_amdgcn_s_barrier();  // ... for every wave; and all are done reading stage (kt-1) % STAGES
+            const char* base = smem + (kt % STAGES) * STAGE;
+            char* nxt = smem + ((kt + STAGES - 1) % STAGES) * STAGE;
+            const int kn = min(kt + STAGES - 1, nk - 1);
+            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            load_frags(base, 0, xf0, wf0);
+            load_frags(base, 1, xf1, wf1);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) stage_piece(i, kn, nxt);
+            mma(xf0, wf0);
+            mma(xf1, wf1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before the block retires
     }
-    {
-        __syncthreads();
-        const char* base = smem + ((nk - 1) & 1) * STAGE;
-        bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
-        load_frags(base, 0, xf0, wf0);
-        load_frags(base, 1, xf1, wf1);
-        mma(xf0, wf0);
-        mma(xf1, wf1);
-    }
-    gemm_epilogue<EPI, MT, GUARD>(a, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
+    GemmArgs e = a;
+    if (EPI == EPI_F32 && a.splits > 1) e.C = (float*)a.C + (size_t)blockIdx.y * M * a.ldc;
+    gemm_epilogue<EPI, MT, GUARD>(e, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
 }
 
-template <int BM, int WMW, int WNW, int EPI, bool GUARD = true>
+template <int BM, int WMW, int WNW, int EPI, bool GUARD = true, int STAGES = 2>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BN = 64 * WNW;
-    constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+    constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, EPI, GUARD>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, EPI, GUARD>), dim3(ntm * ntn), dim3(64 * WMW * WNW), SMEM, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>), dim3(ntm * ntn, a.splits), dim3(64 * WMW * WNW), SMEM, s, a);
     return hipGetLastError();
 }
 
@@ -235,12 +263,14 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
 // 64-71 FLOP per staged byte is near the L2->LDS ceiling: the next step is a larger block tile.
-// Small-M calls (1-view inference) use 128x128 with the guarded epilogue.
+// Small-M calls (1-view inference, CLS-only top-layer backward) are latency-bound: 128x128 with a
+// 4-stage ring (3 K-tiles of DMA in flight) and the guarded epilogue.
 template <int EPI>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
     static int variant = -1;
     if (variant < 0) { const char* v = getenv("TTL_GEMM_VARIANT"); variant = v ? atoi(v) : 2; }
-    if (a.M < 1024 || variant == 0) return launch_t<128, 2, 2, EPI>(a, s);
+    if (a.M < 1024) return (variant == 8) ? launch_t<128, 2, 2, EPI>(a, s) : launch_t<128, 2, 2, EPI, true, 4>(a, s);
+    if (variant == 0) return launch_t<128, 2, 2, EPI>(a, s);
     if (a.padded && EPI != EPI_PATCH) {
         if (variant == 1) return launch_t<320, 4, 2, EPI, false>(a, s);
         return launch_t<160, 2, 2, EPI, false>(a, s);
@@ -250,8 +280,25 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N % 128 || a.K % BK || a.K <= 0 || (a.lda & 7) || (a.ldb & 7)) return hipErrorInvalidValue;
+hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
+    if (a0.M <= 0 || a0.N % 128 || a0.K % BK || a0.K <= 0 || (a0.lda & 7) || (a0.ldb & 7)) return hipErrorInvalidValue;
+    GemmArgs a = a0;
+    a.splits = 1;
+    // Small-M, long-K, fp32-output calls (fc2 / dx of the 1-view inference and of the CLS-only top-layer
+    // backward) put a dozen blocks on 256 CUs: slice K over blockIdx.y into fp32 partial slabs and sum
+    // them in a fixed order (deterministic; no float atomics).
+    if (a.M < 1024 && (epi == EPI_F32 || epi == EPI_RESID_F32) && a.ws && a.K >= 1536) {
+        int sp = 8;
+        while (sp > 1 && ((a.K / BK) % sp || (size_t)sp * a.M * a.N * sizeof(float) > a.ws_bytes)) sp >>= 1;
+        if (sp > 1) {
+            GemmArgs p = a;
+            p.splits = sp; p.C = a.ws; p.ldc = a.N; p.bias = nullptr; p.resid = nullptr;
+            hipError_t e = launch_v<EPI_F32>(p, s);
+            if (e != hipSuccess) return e;
+            return launch_splitk_reduce(a.ws, sp, a.M, a.N, epi == EPI_RESID_F32 ? a.resid : nullptr, a.ldr, a.bias, (float*)a.C,
+                                        a.ldc, s);
+        }
+    }
     switch (epi) {
         case EPI_F32: return launch_v<EPI_F32>(a, s);
         case EPI_BF16: return launch_v<EPI_BF16>(a, s);

@@ -24,6 +24,8 @@ struct GemmArgs {
     bf16_t* C2; int ldc2;         // EPI_GELU second output (pre-activation), may be null
     const bf16_t* aux; int ldaux; // EPI_GELU_BWD: saved pre-activation u
     const float* pos; int G2; int T; // EPI_PATCH
+    float* ws; size_t ws_bytes;   // optional split-K workspace (small-M fp32-output calls)
+    int splits;                   // internal: K slices of this launch (blockIdx.y)
     int padded;                   // all C/resid/aux/C2 buffers have rows up to round_up(M, 320): unguarded epilogue allowed
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
@@ -55,6 +57,9 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* me
                                 int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0,
                                 int stat_stride = 1, int dres_T = 0);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+// out[m][n] = (resid ? resid[m][n] : 0) + (bias ? bias[n] : 0) + sum_s part[s][m][n]   (fixed order: deterministic)
+hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr,
+                                const float* bias, float* out, int ldc, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int ld_out, float* lse, int n, int T,
