@@ -54,6 +54,9 @@ typedef struct ttl_ctx ttl_ctx;
 
 const char* ttl_last_error(void);
 const char* ttl_version(void);
+/* "bf16" (libttl_hip.so, default) or "fp16" (libttl_hip_fp16.so: the reference's autocast dtype, ttl.py:79).
+ * Every "operand" buffer below (qkv, attention out, ...) holds 16-bit values of that type. */
+const char* ttl_operand_dtype(void);
 
 /* Device memory the context will allocate for `cfg` (weights + activation arena), bytes. */
 size_t ttl_workspace_bytes(const ttl_config* cfg);
@@ -150,19 +153,19 @@ typedef struct ttl_episode_args {
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
 
 /* ---- kernel-level entry points (used by the unit parity tests; same kernels as above) ---- */
-/* C[M,N] = A[M,K](bf16, lda) * B[N,K]^T(bf16, ldb) -> fp32 C (ldc).  K % 64 == 0, N % 128 == 0. */
-int ttl_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
+/* C[M,N] = A[M,K](operand dtype, lda) * B[N,K]^T(operand dtype, ldb) -> fp32 C (ldc).  K % 64 == 0, N % 128 == 0. */
+int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
                      int K, void* stream);
 /* y = LayerNorm(x) over the last dim (fp32 in, fp32 out, optional mean/rstd [rows]). */
 int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                       float* rstd, int rows, int dim, float eps, void* stream);
-/* fp32 -> bf16 (round to nearest even). */
-int ttl_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream);
-/* softmax(q k^T / 8) v for head dim 64: qkv bf16 [n*T, 3*H*64] (q | k | v), out bf16 [n*T, H*64],
+/* fp32 -> operand dtype (round to nearest even). */
+int ttl_cast_f32_operand(const float* src, void* dst, size_t n, void* stream);
+/* softmax(q k^T / 8) v for head dim 64: qkv (operand dtype) [n*T, 3*H*64] (q | k | v), out [n*T, H*64],
  * lse fp32 [n,H,T] or NULL. */
 int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n_views, int tokens, int heads,
                       void* stream);
-/* dq,dk,dv of the above: dqkv bf16 [n*T, ld_dqkv] (dq | dk | dv); need_dk == 0 skips dk. */
+/* dq,dk,dv of the above: dqkv (operand dtype) [n*T, ld_dqkv] (dq | dk | dv); need_dk == 0 skips dk. */
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                       int ld_dqkv, int n_views, int tokens, int heads, int need_dk, void* stream);
 

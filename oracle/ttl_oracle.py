@@ -19,9 +19,10 @@ and is called from the reference at clip/custom_clip.py:62-71, :665-694, deyo.py
 ttl.py:50-61, :70-110, :189-220.
 
 ``prec="fp32"`` is the reference semantics (CPU path of the reference is pure fp32, Q14).
-``prec="bf16"`` rounds every matrix-multiply operand to bfloat16 at the points where the
-HIP path does while keeping fp32 accumulation; it is the tight checker for
-the kernels, and the distance between the two modes is the price of bf16 MFMA.
+``prec="bf16"`` / ``prec="fp16"`` round every matrix-multiply operand to that 16-bit type at the
+points where the HIP path does while keeping fp32 accumulation; they are the
+tight checkers for the two library builds, and their distance to "fp32" is the price of the
+16-bit MFMA operands.
 """
 import math
 
@@ -43,11 +44,19 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
     return out
 
 
+def fp16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> IEEE half -> fp32 (round to nearest even; overflow -> inf like v_cvt_f16_f32)."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
 def _rounder(prec):
     if prec == "fp32":
         return lambda a: a
     if prec == "bf16":
         return bf16_round
+    if prec == "fp16":
+        return fp16_round
     raise ValueError(prec)
 
 

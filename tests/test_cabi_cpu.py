@@ -9,17 +9,22 @@ from ttl_amd import _lib
 
 
 def test_library_is_built_in_tree():
-    assert os.path.exists(_lib.LIB_PATH), "run `python __graft_entry__.py` (or make -C .../csrc) first"
+    for p in _lib.LIB_PATHS.values():
+        assert os.path.exists(p), "run `python __graft_entry__.py` (or make -C .../csrc) first"
+    with pytest.raises(_lib.TtlError):
+        _lib.load("fp8")
 
 
-def test_exports_match_header():
-    lib = _lib.load()
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_exports_match_header(precision):
+    lib = _lib.load(precision)
     declared = _lib.header_symbols()
     assert len(declared) >= 20
     assert set(declared) == set(_lib.SIGNATURES), "ctypes table and header disagree"
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.ttl_version().startswith(b"ttl_hip")
+    assert lib.ttl_operand_dtype() == precision.encode()
 
 
 def test_config_validation_without_gpu():

@@ -43,7 +43,7 @@ def test_gemm_bf16_nt(lib, M, N, K):
     ref = a.float().numpy() @ b.float().numpy().T
     da, db = a.cuda(), b.cuda()
     c = torch.full((M, N), float("nan"), device="cuda")
-    chk(lib, lib.ttl_gemm_bf16_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
+    chk(lib, lib.ttl_gemm_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
     torch.cuda.synchronize()
     out = c.cpu().numpy()
     assert np.isfinite(out).all()
@@ -59,7 +59,7 @@ def test_gemm_layout_asymmetric(lib):
     b = (torch.arange(N * K).reshape(N, K) % 251).float() - 100.0
     c = torch.empty(M, N, device="cuda")
     da, db = a.to(torch.bfloat16).cuda(), b.to(torch.bfloat16).cuda()
-    chk(lib, lib.ttl_gemm_bf16_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
+    chk(lib, lib.ttl_gemm_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
     torch.cuda.synchronize()
     assert np.array_equal(c.cpu().numpy(), (a @ b.T).numpy())
 

@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 CASES = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo"]
 
 
-def make_engine(cfg, W, lora0, tf, n_views):
+def make_engine(cfg, W, lora0, tf, n_views, precision="bf16"):
     from ttl_amd.engine import TTLEngine
-    eng = TTLEngine(cfg, max_views=n_views, max_classes=tf.shape[0], device="cuda:0")
+    eng = TTLEngine(cfg, max_views=n_views, max_classes=tf.shape[0], device="cuda:0", precision=precision)
     eng.load_weights(W)
     eng.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
     names = O.trainable_names(cfg)
@@ -228,3 +228,54 @@ def test_r32_128_views_multi_step_invariants():
     assert max_rel(full.cpu().numpy(), a.cpu().numpy()) < 2e-3
     assert torch.isfinite(a).all()
     eng.close()
+
+
+# ------------------------------------------------------------------ fp16-operand build (the reference's autocast dtype)
+@pytest.mark.parametrize("name", ["tiny_deyo", "tiny197_deyo", "b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1"])
+def test_fp16_operands_meet_the_1e3_tolerance(name):
+    """libttl_hip_fp16.so: same kernels with IEEE-half MFMA operands (what torch.cuda.amp.autocast() uses in
+    the reference's GPU path, ttl.py:79) and a fixed 2^10 loss scale in the backward (cf. GradScaler,
+    ttl.py:222).  BASELINE.json's tolerance: logits and LoRA weights within 1e-3 (relative to the tensor's
+    range) of the reference, selection mask bit-exact."""
+    g, cfg, W, x, lora0, tf = load_case(name)
+    kw = episode_kwargs(g)
+    eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision="fp16")
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    l1, l0 = eng.episode(torch.from_numpy(x).cuda(), snap, m, v, n_updates=kw["n_updates"], objective=kw["objective"],
+                         mode=1 if kw["mode"] == "topk" else 0, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"],
+                         want_logits0=True)
+    torch.cuda.synchronize()
+    z0 = l0.cpu().numpy()
+    TOL = 1e-3
+    assert max_rel(z0, g["logits0"]) < TOL, max_rel(z0, g["logits0"])
+    H = O.softmax_entropy(z0)
+    idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
+    assert np.array_equal(np.sort(idx), np.sort(g["idx"]))
+    lora1 = split(flat, lora0, names)
+    grads = split(eng.grads, lora0, names)
+    for k in names:
+        gref = g["grad/" + k]
+        if np.abs(gref).max() == 0:
+            assert not grads[k].any(), k
+            assert np.abs(lora1[k] - g["lora1/" + k]).max() < 1e-7, k
+        else:
+            assert max_rel(grads[k], gref) < 3e-3, (k, max_rel(grads[k], gref))
+            dg = np.abs(grads[k] - gref).max() * 1.001
+            check_lora_step(lora1[k], g["lora1/" + k], gref, kw["lr"], TOL, k, dg=dg)
+            # every element further than TOL from the reference must be one whose gradient is smaller than
+            # the gradient error (sign-like first step, Q11) -- check_lora_step above enforces exactly that
+    assert max_rel(l1.cpu().numpy(), g["logits1"]) < TOL, max_rel(l1.cpu().numpy(), g["logits1"])
+    assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
+    eng.close()
+
+
+def test_fp16_and_bf16_builds_coexist():
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    e1, f1, _ = make_engine(cfg, W, lora0, tf, x.shape[0], "bf16")
+    e2, f2, _ = make_engine(cfg, W, lora0, tf, x.shape[0], "fp16")
+    xd = torch.from_numpy(x).cuda()
+    a, b = e1.forward(xd).cpu().numpy(), e2.forward(xd).cpu().numpy()
+    assert e1.lib.ttl_operand_dtype() == b"bf16" and e2.lib.ttl_operand_dtype() == b"fp16"
+    assert max_rel(b, g["logits0"]) < max_rel(a, g["logits0"])         # fp16 is the more accurate of the two
+    assert 1e-5 < max_rel(a, b) < 2e-2                                   # and they really are different builds
+    e1.close(); e2.close()

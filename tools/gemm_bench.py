@@ -14,12 +14,12 @@ for (M, N, K) in shapes:
     c = torch.empty(M, N, device="cuda")
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
-        lib.ttl_gemm_bf16_nt(P(a), K, P(b), K, P(c), N, M, N, K, s)
+        lib.ttl_gemm_nt(P(a), K, P(b), K, P(c), N, M, N, K, s)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     it = 20
     e0.record()
     for _ in range(it):
-        lib.ttl_gemm_bf16_nt(P(a), K, P(b), K, P(c), N, M, N, K, s)
+        lib.ttl_gemm_nt(P(a), K, P(b), K, P(c), N, M, N, K, s)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / it

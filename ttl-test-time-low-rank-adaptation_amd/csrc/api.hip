@@ -42,25 +42,25 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Layer {
     // forward images
-    bf16_t* wqkv;   // [3D][ldw]
+    op_t* wqkv;   // [3D][ldw]
     float* bqkv;    // [3D]
-    bf16_t* wo;     // [D][D]
+    op_t* wo;     // [D][D]
     float* bo;
-    bf16_t* w1;     // [F][D]
+    op_t* w1;     // [F][D]
     float* b1;
-    bf16_t* w2;     // [D][F]
+    op_t* w2;     // [D][F]
     float* b2;
     float *ln1g, *ln1b, *ln2g, *ln2b;
     // dgrad images (trained layers only)
-    bf16_t* wqkvT;  // [D][ldwt]
-    bf16_t* woT;    // [D][D]   (= Wo^T: [in][out] -> rows = in)
-    bf16_t* w1T;    // [D][F]
-    bf16_t* w2T;    // [F][D]
-    bf16_t* acat;   // [2r][D]
-    bf16_t* btcat;  // [2r][D]
+    op_t* wqkvT;  // [D][ldwt]
+    op_t* woT;    // [D][D]   (= Wo^T: [in][out] -> rows = in)
+    op_t* w1T;    // [D][F]
+    op_t* w2T;    // [F][D]
+    op_t* acat;   // [2r][D]
+    op_t* btcat;  // [2r][D]
     // saved activations (trained layers only)
     float* h_in; float* h_mid;
-    bf16_t* x1ext; bf16_t* qkv; bf16_t* attn; bf16_t* u;
+    op_t* x1ext; op_t* qkv; op_t* attn; op_t* u;
     float* lse; float *mu1, *rs1, *mu2, *rs2;
     bool trained;
     unsigned loaded;  // bitmask of loaded tensors
@@ -77,7 +77,7 @@ struct ttl_ctx {
     size_t bytes = 0;
     std::vector<Layer> layers;
     // embeddings / head
-    bf16_t* wpatch;  // [D][Kp]
+    op_t* wpatch;  // [D][Kp]
     float *cls, *pos, *preg, *preb, *postg, *postb;
     float *wp, *wpT;  // [E][D], [D][E]
     unsigned head_loaded = 0;
@@ -88,14 +88,14 @@ struct ttl_ctx {
     // lora binding
     float* lora_p = nullptr; float* lora_g = nullptr; size_t lora_n = 0;
     // shared activations
-    bf16_t* patches; float* h;  // running residual stream
+    op_t* patches; float* h;  // running residual stream
     float* h_out[8];             // outputs of trained layers (h_out[i] = input of the next one)
-    bf16_t *x1, *qkv, *attn, *x2, *g;
+    op_t *x1, *qkv, *attn, *x2, *g;
     float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits, *head_te, *head_td;
     // backward scratch
-    float *dh, *dh2, *dx; bf16_t *dh16, *dbig, *dattn, *dqkv;
+    float *dh, *dh2, *dx; op_t *dh16, *dbig, *dattn, *dqkv;
     // top-layer backward works on the CLS rows only (compact [N, .] buffers)
-    float *dcls, *dxc, *dhmc; bf16_t *dcls16, *dgc, *dhmc16, *doc;
+    float *dcls, *dxc, *dhmc; op_t *dcls16, *dgc, *dhmc16, *doc;
     float* wg_partial;
     float* gemm_ws; size_t gemm_ws_bytes;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
@@ -186,10 +186,12 @@ enum { HW_CLS = 1, HW_PATCH = 2, HW_POS = 4, HW_PREG = 8, HW_PREB = 16, HW_POSTG
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* ttl_last_error(void) { return g_err; }
-const char* ttl_version(void) { return "ttl_hip 0.1 (gfx950)"; }
+const char* ttl_version(void) { return "ttl_hip 0.2 (gfx950, " TTL_OPERAND_NAME " operands)"; }
+const char* ttl_operand_dtype(void) { return TTL_OPERAND_NAME; }
 
 size_t ttl_workspace_bytes(const ttl_config* k) {
     if (check_config(k)) return 0;
@@ -302,19 +304,19 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
         auto proj_w = [&](int which, unsigned bit) -> int {  // q/k/v weight [D][D] -> rows which*D.. of wqkv (+ transposed image)
             NEED(D * D);
             if ((rc = upload(c, data, count, &tmp))) return rc;
-            hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)D, l.wqkv + (size_t)which * D * c->ldw, c->ldw, s);
-            if (e == hipSuccess && l.trained) e = launch_transpose_f32_bf16(tmp, (int)D, (int)D, l.wqkvT + (size_t)which * D, c->ldwt, s);
+            hipError_t e = launch_cast_rows_f32_op(tmp, (int)D, (int)D, l.wqkv + (size_t)which * D * c->ldw, c->ldw, s);
+            if (e == hipSuccess && l.trained) e = launch_transpose_f32_op(tmp, (int)D, (int)D, l.wqkvT + (size_t)which * D, c->ldwt, s);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             (void)hipFree(tmp);
             if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
             l.loaded |= bit;
             return 0;
         };
-        auto plain_w = [&](bf16_t* dst, bf16_t* dstT, size_t rows, size_t cols, unsigned bit) -> int {
+        auto plain_w = [&](op_t* dst, op_t* dstT, size_t rows, size_t cols, unsigned bit) -> int {
             NEED(rows * cols);
             if ((rc = upload(c, data, count, &tmp))) return rc;
-            hipError_t e = launch_cast_f32_bf16(tmp, dst, count, s);
-            if (e == hipSuccess && dstT) e = launch_transpose_f32_bf16(tmp, (int)rows, (int)cols, dstT, (int)rows, s);
+            hipError_t e = launch_cast_f32_op(tmp, dst, count, s);
+            if (e == hipSuccess && dstT) e = launch_transpose_f32_op(tmp, (int)rows, (int)cols, dstT, (int)rows, s);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             (void)hipFree(tmp);
             if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
@@ -345,7 +347,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
         size_t kk = 3 * (size_t)c->P * c->P;
         NEED(D * kk);
         if ((rc = upload(c, data, count, &tmp))) return rc;
-        hipError_t e = launch_cast_rows_f32_bf16(tmp, (int)D, (int)kk, c->wpatch, c->Kp, s);
+        hipError_t e = launch_cast_rows_f32_op(tmp, (int)D, (int)kk, c->wpatch, c->Kp, s);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         (void)hipFree(tmp);
         if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
@@ -471,10 +473,10 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         Layer& l = c->layers[i];
         const bool tr = l.trained;          // LoRA path active (B == 0 forever in the other layers, Q10)
         const bool sv = tr && save;
-        bf16_t* x1 = tr ? l.x1ext : c->x1;
+        op_t* x1 = tr ? l.x1ext : c->x1;
         const int ldx1 = tr ? c->ldx : D;
-        bf16_t* qkv = tr ? l.qkv : c->qkv;
-        bf16_t* att = tr ? l.attn : c->attn;
+        op_t* qkv = tr ? l.qkv : c->qkv;
+        op_t* att = tr ? l.attn : c->attn;
         float* h_in = h;  // trained layers write h_mid / h_out to fresh buffers, so h_in survives for LN1 backward
         {
             Prof p(c, 3, s);
@@ -488,7 +490,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             GemmArgs a = {};
             a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = tr ? D + 64 : D;
             a.C = qkv; a.ldc = 3 * D; a.bias = l.bqkv;
-            if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+            if ((rc = gemm(c, EPI_OP, a, s))) return rc;
         }
         {
             Prof p(c, 1, s);
@@ -610,7 +612,7 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
                 GemmArgs a = {};
                 a.A = c->dhmc16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = n; a.N = D; a.K = D;
                 a.C = c->doc; a.ldc = D;
-                if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+                if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
                 Prof p(c, 2, s);
@@ -640,7 +642,7 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
                 GemmArgs a = {};
                 a.A = c->dh16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = M; a.N = D; a.K = D;
                 a.C = c->dattn; a.ldc = D;
-                if ((rc = gemm(c, EPI_BF16, a, s))) return rc;
+                if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
                 Prof p(c, 2, s);
@@ -720,9 +722,9 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ kernel-level entry points
-int ttl_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
+int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
     GemmArgs a = {};
-    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
     hipError_t e = launch_gemm(EPI_F32, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));
     return 0;
@@ -734,19 +736,19 @@ int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, flo
     return 0;
 }
 
-int ttl_cast_f32_bf16(const float* src, void* dst, size_t n, void* stream) {
-    HIP_TRY(launch_cast_f32_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream));
+int ttl_cast_f32_operand(const float* src, void* dst, size_t n, void* stream) {
+    HIP_TRY(launch_cast_f32_op(src, (op_t*)dst, n, (hipStream_t)stream));
     return 0;
 }
 
 int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n, int T, int H, void* stream) {
-    HIP_TRY(launch_attention_fwd((const bf16_t*)qkv, 3 * H * 64, (bf16_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream));
+    HIP_TRY(launch_attention_fwd((const op_t*)qkv, 3 * H * 64, (op_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream));
     return 0;
 }
 
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int ld_dqkv, int n, int T,
                       int H, int need_dk, void* stream) {
-    HIP_TRY(launch_attention_bwd((const bf16_t*)qkv, 3 * H * 64, (const bf16_t*)out, (const bf16_t*)dout, H * 64, lse, (bf16_t*)dqkv,
+    HIP_TRY(launch_attention_bwd((const op_t*)qkv, 3 * H * 64, (const op_t*)out, (const op_t*)dout, H * 64, lse, (op_t*)dqkv,
                                  ld_dqkv, n, T, H, need_dk, (hipStream_t)stream));
     return 0;
 }
@@ -810,3 +812,4 @@ int ttl_profile_read(ttl_ctx* c, double ms[TTL_NCLASS], long long launches[TTL_N
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

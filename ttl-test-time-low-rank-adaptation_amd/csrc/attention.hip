@@ -26,12 +26,12 @@ __device__ __forceinline__ int tile_off(int row, int col) {
 // DMA rows [0,TP) of a [T][64] bf16 matrix (row stride ld elements) into a swizzled LDS tile;
 // rows >= T replicate row T-1 (finite data; their results are masked).
 template <int NKT>
-__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* g, int ld, int T, int tid, int wave) {
+__device__ __forceinline__ void stage_tile(char* lds, const op_t* g, int ld, int T, int tid, int wave) {
 #pragma unroll
     for (int i = 0; i < NKT; ++i) {  // 32 rows x 8 chunks = 256 chunks per pass
         int q = i * 256 + tid, r = q >> 3, p = q & 7;
         int c = p ^ swz(r);
-        const bf16_t* src = g + (size_t)min(r, T - 1) * ld + c * 8;
+        const op_t* src = g + (size_t)min(r, T - 1) * ld + c * 8;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
     }
 }
@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* g, int ld, i
 // A-operand fragment of X^T for k-step (rows kb..kb+15 of the row-major tile X, columns
 // cb..cb+31), in the k order of an accumulator-derived B operand:
 //   element j of lane half h  <->  row kb + 8*(j>>2) + 4*h + (j&3),  column cb + (lane&31)
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int lane) {
+__device__ __forceinline__ opx8 tr_frag(const char* tile, int kb, int cb, int lane) {
     const int h = lane >> 5, grp = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
     const int col = cb + 16 * grp + 4 * p;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -48,37 +48,37 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kb, int cb, int 
         (__attribute__((address_space(3))) s16x4*)(tile + tile_off(kb + 8 + 4 * h + q, col)));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(opx8, v);
 }
 
 // row-read fragment: rows rb + (lane&31), 16-B chunk 2*ks + (lane>>5)
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int ks, int lane) {
+__device__ __forceinline__ opx8 row_frag(const char* tile, int rb, int ks, int lane) {
     const int r = rb + (lane & 31), c = 2 * ks + (lane >> 5);
-    return *(const bf16x8*)(tile + r * 128 + ((c ^ swz(r)) << 4));
+    return *(const opx8*)(tile + r * 128 + ((c ^ swz(r)) << 4));
 }
 
-__device__ __forceinline__ bf16x8 global_frag(const bf16_t* g, int ld, int row, int ks, int lane) {
-    return *(const bf16x8*)(g + (size_t)row * ld + 16 * ks + 8 * (lane >> 5));
+__device__ __forceinline__ opx8 global_frag(const op_t* g, int ld, int row, int ks, int lane) {
+    return *(const opx8*)(g + (size_t)row * ld + 16 * ks + 8 * (lane >> 5));
 }
 
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16 operand fragment of k-step s
-__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
-    u32x4 v = {pack_bf16x2(a[8 * s], a[8 * s + 1]), pack_bf16x2(a[8 * s + 2], a[8 * s + 3]),
-               pack_bf16x2(a[8 * s + 4], a[8 * s + 5]), pack_bf16x2(a[8 * s + 6], a[8 * s + 7])};
-    return __builtin_bit_cast(bf16x8, v);
+__device__ __forceinline__ opx8 acc_frag(const f32x16& a, int s) {
+    u32x4 v = {pack_op2(a[8 * s], a[8 * s + 1]), pack_op2(a[8 * s + 2], a[8 * s + 3]),
+               pack_op2(a[8 * s + 4], a[8 * s + 5]), pack_op2(a[8 * s + 6], a[8 * s + 7])};
+    return __builtin_bit_cast(opx8, v);
 }
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // store a [64 x 32] transposed accumulator pair (rows = head-dim, column = this lane's token)
-__device__ __forceinline__ void store_ot(bf16_t* dst_row, const f32x16 (&o)[2], float mul, int lane) {
+__device__ __forceinline__ void store_ot(op_t* dst_row, const f32x16 (&o)[2], float mul, int lane) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int dh = 32 * dt + 8 * g + 4 * (lane >> 5);
-            *(u32x2*)(dst_row + dh) = u32x2{pack_bf16x2(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul),
-                                            pack_bf16x2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
+            *(u32x2*)(dst_row + dh) = u32x2{pack_op2(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul),
+                                            pack_op2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
         }
 }
 
@@ -86,7 +86,7 @@ constexpr float SCALE = 0.125f;  // head_dim^-0.5, head_dim = 64
 
 // ------------------------------------------------------------------------------ forward
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
                                                        int ldo, float* __restrict__ lse, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
-    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
     stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
     stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
     __syncthreads();
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int nqb = (T + 31) >> 5;
     for (int qb = wave; qb < nqb; qb += 4) {
         const int qrow = min(qb * 32 + (lane & 31), T - 1);
-        bf16x8 qf[4];
+        opx8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = global_frag(qg, ld, qrow, ks, lane);
         f32x16 st[NKT];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             f32x16 a = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+                a = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = (32 * kt + acc_row(r, lane) < T) ? a[r] * SCALE : -INFINITY;
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 pf = acc_frag(st[kt], s);
+                opx8 pf = acc_frag(st[kt], s);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, 32 * kt + 16 * s, 32 * dt, lane), pf,
+                    o[dt] = MFMA32(tr_frag(sV, 32 * kt + 16 * s, 32 * dt, lane), pf,
                                                                     o[dt], 0, 0, 0);
             }
         const int q = qb * 32 + (lane & 31);
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // ------------------------------------------------------------------------------ backward: dQ
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, int ld,
-                                                          const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
+                                                          const op_t* __restrict__ out, const op_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dqkv, int ldd, int T, int H) {
+                                                          op_t* __restrict__ dqkv, int ldd, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
     char* sK = smem;
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
-    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
-    const bf16_t* og = out + (size_t)img * T * ldo + head * 64;
-    const bf16_t* dog = dout + (size_t)img * T * ldo + head * 64;
+    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const op_t* og = out + (size_t)img * T * ldo + head * 64;
+    const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
     stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
     stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
     __syncthreads();
@@ -178,13 +178,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int qb = wave; qb < nqb; qb += 4) {
         const int q = qb * 32 + (lane & 31);
         const int qrow = min(q, T - 1);
-        bf16x8 qf[4], dof[4];
+        opx8 qf[4], dof[4];
         float delta = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks] = global_frag(qg, ld, qrow, ks, lane);
             dof[ks] = global_frag(dog, ldo, qrow, ks, lane);
-            bf16x8 of = global_frag(og, ldo, qrow, ks, lane);
+            opx8 of = global_frag(og, ldo, qrow, ks, lane);
 #pragma unroll
             for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
         }
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             f32x16 s = {}, dp = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 32 * kt, ks, lane), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+                s = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = MFMA32(row_frag(sV, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
-                bf16x8 dsf = acc_frag(s, sb);
+                opx8 dsf = acc_frag(s, sb);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, 32 * kt + 16 * sb, 32 * dt, lane), dsf,
+                    dq[dt] = MFMA32(tr_frag(sK, 32 * kt + 16 * sb, 32 * dt, lane), dsf,
                                                                      dq[dt], 0, 0, 0);
             }
         }
@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 // ------------------------------------------------------------------------------ backward: dK, dV
 template <int NKT, bool NEED_DK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, int ld,
-                                                           const bf16_t* __restrict__ out,
-                                                           const bf16_t* __restrict__ dout, int ldo,
-                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const op_t* __restrict__ qkv, int ld,
+                                                           const op_t* __restrict__ out,
+                                                           const op_t* __restrict__ dout, int ldo,
+                                                           const float* __restrict__ lse, op_t* __restrict__ dqkv,
                                                            int ldd, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
-    const bf16_t* qg = qkv + (size_t)img * T * ld + head * 64;
-    const bf16_t* og = out + (size_t)img * T * ldo + head * 64;
-    const bf16_t* dog = dout + (size_t)img * T * ldo + head * 64;
+    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const op_t* og = out + (size_t)img * T * ldo + head * 64;
+    const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
     stage_tile<NKT>(sQ, qg, ld, T, tid, wave);
     stage_tile<NKT>(sDO, dog, ldo, T, tid, wave);
     for (int t = tid; t < TP; t += 256) {
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            bf16x8 a = *(const bf16x8*)(dog + (size_t)row * ldo + 8 * c);
-            bf16x8 b = *(const bf16x8*)(og + (size_t)row * ldo + 8 * c);
+            opx8 a = *(const opx8*)(dog + (size_t)row * ldo + 8 * c);
+            opx8 b = *(const opx8*)(og + (size_t)row * ldo + 8 * c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)b[j];
         }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int kb = wave; kb < nkb; kb += 4) {
         const int key = kb * 32 + (lane & 31);
         const int krow = min(key, T - 1);
-        bf16x8 kf[4], vf[4];
+        opx8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             kf[ks] = global_frag(qg + D, ld, krow, ks, lane);
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             f32x16 s = {}, dp = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+                s = MFMA32(row_frag(sQ, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = MFMA32(row_frag(sDO, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
             }
             f32x16 ds;
 #pragma unroll
@@ -283,20 +283,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
-                bf16x8 pf = acc_frag(s, sb);
-                bf16x8 dsf = acc_frag(ds, sb);
+                opx8 pf = acc_frag(s, sb);
+                opx8 dsf = acc_frag(ds, sb);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDO, 32 * qt + 16 * sb, 32 * dt, lane), pf,
+                    dv[dt] = MFMA32(tr_frag(sDO, 32 * qt + 16 * sb, 32 * dt, lane), pf,
                                                                      dv[dt], 0, 0, 0);
                     if (NEED_DK)
-                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, 32 * qt + 16 * sb, 32 * dt, lane),
+                        dk[dt] = MFMA32(tr_frag(sQ, 32 * qt + 16 * sb, 32 * dt, lane),
                                                                          dsf, dk[dt], 0, 0, 0);
                 }
             }
         }
         if (key < T) {
-            bf16_t* base = dqkv + (size_t)(img * T + key) * ldd + head * 64;
+            op_t* base = dqkv + (size_t)(img * T + key) * ldd + head * 64;
             store_ot(base + 2 * D, dv, 1.0f, lane);
             if (NEED_DK) store_ot(base + D, dk, SCALE, lane);
         }
@@ -309,21 +309,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 //   p_j = exp(q0.k_j/8 - lse0), dp_j = do0.v_j, ds_j = p_j (dp_j - do0.o0),
 //   dq_0 = sum_j ds_j k_j / 8,  dk_j = ds_j q0 / 8,  dv_j = p_j do0;   dq_t = 0 for t > 0.
 template <bool NEED_DK>
-__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ out,
-                                                           int ldo, const bf16_t* __restrict__ dout_cls,
-                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int ldd,
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restrict__ qkv, int ld, const op_t* __restrict__ out,
+                                                           int ldo, const op_t* __restrict__ dout_cls,
+                                                           const float* __restrict__ lse, op_t* __restrict__ dqkv, int ldd,
                                                            int T, int H) {
     __shared__ float sq[64], sdo[64], sds[320], sred[4][64];
     __shared__ float sdelta;
     const int tid = threadIdx.x;
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
-    const bf16_t* base = qkv + (size_t)img * T * ld + head * 64;
+    const op_t* base = qkv + (size_t)img * T * ld + head * 64;
     if (tid < 64) {
-        sq[tid] = bf16_to_f32(base[tid]);
-        float d = bf16_to_f32(dout_cls[(size_t)img * D + head * 64 + tid]);
+        sq[tid] = op_to_f32(base[tid]);
+        float d = op_to_f32(dout_cls[(size_t)img * D + head * 64 + tid]);
         sdo[tid] = d;
-        float prod = d * bf16_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]);
+        float prod = d * op_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]);
         prod = wave_sum(prod);
         if (tid == 0) sdelta = prod;
     }
@@ -331,28 +331,28 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16_t* __restr
     const float l0 = lse[((size_t)img * H + head) * T];
     const float delta = sdelta;
     for (int j = tid; j < T; j += 256) {
-        const bf16_t* kr = base + (size_t)j * ld + D;
-        const bf16_t* vr = base + (size_t)j * ld + 2 * D;
+        const op_t* kr = base + (size_t)j * ld + D;
+        const op_t* vr = base + (size_t)j * ld + 2 * D;
         float s = 0.f, dp = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            bf16x8 kf = *(const bf16x8*)(kr + 8 * c), vf = *(const bf16x8*)(vr + 8 * c);
+            opx8 kf = *(const opx8*)(kr + 8 * c), vf = *(const opx8*)(vr + 8 * c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s = fmaf(sq[8 * c + e], (float)kf[e], s); dp = fmaf(sdo[8 * c + e], (float)vf[e], dp); }
         }
         const float p = __expf(s * SCALE - l0);
         // the MFMA path rounds P and dS to bf16 before the second products; keep the same points
-        const float pb = bf16_to_f32(f32_to_bf16(p));
-        const float ds = bf16_to_f32(f32_to_bf16(p * (dp - delta)));
+        const float pb = op_to_f32(f32_to_op(p));
+        const float ds = op_to_f32(f32_to_op(p * (dp - delta)));
         sds[j] = ds;
-        bf16_t* o = dqkv + (size_t)(img * T + j) * ldd + head * 64;
+        op_t* o = dqkv + (size_t)(img * T + j) * ldd + head * 64;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             u32x4 dv, dk, z = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dv[e] = pack_bf16x2(pb * sdo[8 * c + 2 * e], pb * sdo[8 * c + 2 * e + 1]);
-                dk[e] = pack_bf16x2(ds * sq[8 * c + 2 * e] * SCALE, ds * sq[8 * c + 2 * e + 1] * SCALE);
+                dv[e] = pack_op2(pb * sdo[8 * c + 2 * e], pb * sdo[8 * c + 2 * e + 1]);
+                dk[e] = pack_op2(ds * sq[8 * c + 2 * e] * SCALE, ds * sq[8 * c + 2 * e + 1] * SCALE);
             }
             *(u32x4*)(o + 2 * D + 8 * c) = dv;
             if (NEED_DK) *(u32x4*)(o + D + 8 * c) = dk;
@@ -364,13 +364,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16_t* __restr
     {
         const int d = tid & 63, w = tid >> 6;
         float acc = 0.f;
-        for (int j = w; j < T; j += 4) acc = fmaf(sds[j], bf16_to_f32(base[(size_t)j * ld + D + d]), acc);
+        for (int j = w; j < T; j += 4) acc = fmaf(sds[j], op_to_f32(base[(size_t)j * ld + D + d]), acc);
         sred[w][d] = acc;
     }
     __syncthreads();
     if (tid < 64) {
         float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
-        dqkv[(size_t)(img * T) * ldd + head * 64 + tid] = f32_to_bf16(v * SCALE);
+        dqkv[(size_t)(img * T) * ldd + head * 64 + tid] = f32_to_op(v * SCALE);
     }
 }
 
@@ -380,7 +380,7 @@ hipError_t set_smem(K kernel, int bytes) {
 }
 
 template <int NKT>
-hipError_t fwd_t(const bf16_t* qkv, int ld, bf16_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
     static bool done = false;
     if (!done) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done = true; }
@@ -389,8 +389,8 @@ hipError_t fwd_t(const bf16_t* qkv, int ld, bf16_t* out, int ldo, float* lse, in
 }
 
 template <int NKT>
-hipError_t bwd_t(const bf16_t* qkv, int ld, const bf16_t* out, const bf16_t* dout, int ldo, const float* lse,
-                 bf16_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s) {
+hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
+                 op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s) {
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
     constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
     static bool done = false;
@@ -414,7 +414,7 @@ hipError_t bwd_t(const bf16_t* qkv, int ld, const bf16_t* out, const bf16_t* dou
 
 }  // namespace
 
-hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int ld_out, float* lse, int n, int T, int H,
+hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                 hipStream_t s) {
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
@@ -425,8 +425,8 @@ hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out, const bf16_t* dout, int ld_o,
-                                const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
+                                const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s) {
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return bwd_t<1>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
@@ -437,8 +437,8 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_attention_bwd_cls(const bf16_t* qkv, int ld_qkv, const bf16_t* out, int ld_o, const bf16_t* dout_cls,
-                                    const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
+                                    const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s) {
     if (T > 320) return hipErrorInvalidValue;
     if (need_dk)

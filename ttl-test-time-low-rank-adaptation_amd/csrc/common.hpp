@@ -3,8 +3,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // storage type; arithmetic is always fp32
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// ---- operand type of every MFMA product (activations, weights, attention probabilities).
+// Default build: bf16 (BASELINE.json north_star).  -DTTL_OPERAND_FP16 builds libttl_hip_fp16.so with
+// IEEE half operands — the dtype of the reference's own GPU path (torch.cuda.amp.autocast(), ttl.py:79)
+// — same MFMA rate, 3 more mantissa bits; its backward carries a fixed 2^10 loss scale like the
+// reference's GradScaler(init_scale=1000) (ttl.py:222).  Accumulation is fp32 in both.
+typedef uint16_t op_t;  // storage type; arithmetic is always fp32
+#ifdef TTL_OPERAND_FP16
+typedef _Float16 op_scalar;
+#define TTL_OPERAND_NAME "fp16"
+#define TTL_GRAD_SCALE 1024.0f
+#define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#else
+typedef __bf16 op_scalar;
+#define TTL_OPERAND_NAME "bf16"
+#define TTL_GRAD_SCALE 1.0f
+#define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#endif
+typedef __attribute__((ext_vector_type(8))) op_scalar opx8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -14,20 +32,26 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
-
-// round-to-nearest-even fp32 -> bf16 (plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN stays NaN)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    __bf16 b = (__bf16)f;
+// fp32 -> operand, round to nearest even (plain cast: hipcc emits v_cvt_pk_bf16_f32 / v_cvt_f16_f32;
+// NaN stays NaN)
+__device__ __forceinline__ op_t f32_to_op(float f) {
+    op_scalar b = (op_scalar)f;
     return __builtin_bit_cast(uint16_t, b);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) op_scalar op2;
+    op2 v = {(op_scalar)lo, (op_scalar)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+#ifdef TTL_OPERAND_FP16
+__device__ __forceinline__ float op_to_f32(op_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float op_lo(uint32_t w) { return op_to_f32((op_t)(w & 0xFFFFu)); }
+__device__ __forceinline__ float op_hi(uint32_t w) { return op_to_f32((op_t)(w >> 16)); }
+#else
+__device__ __forceinline__ float op_to_f32(op_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float op_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float op_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

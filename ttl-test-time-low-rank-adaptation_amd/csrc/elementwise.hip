@@ -6,28 +6,28 @@
 
 namespace {
 
-__global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+__global__ void cast_kernel(const float* __restrict__ src, op_t* __restrict__ dst, size_t n) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     size_t stride = (size_t)gridDim.x * blockDim.x * 8;
     for (; i + 8 <= n; i += stride) {
         float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
-        *(u32x4*)(dst + i) = u32x4{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+        *(u32x4*)(dst + i) = u32x4{pack_op2(a.x, a.y), pack_op2(a.z, a.w), pack_op2(b.x, b.y), pack_op2(b.z, b.w)};
     }
     // tail (n % 8) handled by the first thread
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (size_t j = n & ~(size_t)7; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+        for (size_t j = n & ~(size_t)7; j < n; ++j) dst[j] = f32_to_op(src[j]);
 }
 
-__global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst, int ld) {
+__global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, op_t* __restrict__ dst, int ld) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)rows * cols;
     if (i >= n) return;
     int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
-    dst[(size_t)r * ld + c] = f32_to_bf16(src[i]);
+    dst[(size_t)r * ld + c] = f32_to_op(src[i]);
 }
 
 // 32x32 LDS-tiled transpose + cast
-__global__ void transpose_kernel(const float* __restrict__ src, int R, int C, bf16_t* __restrict__ dst, int ld) {
+__global__ void transpose_kernel(const float* __restrict__ src, int R, int C, op_t* __restrict__ dst, int ld) {
     __shared__ float tile[32][33];
     int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
@@ -38,13 +38,13 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int C, bf
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         int c = c0 + j, r = r0 + tx;  // dst[c][r]
-        if (c < C && r < R) dst[(size_t)c * ld + r] = f32_to_bf16(tile[tx][j]);
+        if (c < C && r < R) dst[(size_t)c * ld + r] = f32_to_op(tile[tx][j]);
     }
 }
 
 // One thread converts 8 consecutive pixels of one image row: 32 B coalesced reads, 16 B writes
 // landing in the patch-major im2col matrix the patch GEMM consumes.
-__global__ void im2col_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int n, int S, int P, int Kp) {
+__global__ void im2col_kernel(const float* __restrict__ x, op_t* __restrict__ out, int n, int S, int P, int Kp) {
     const int G = S / P;
     const int W8 = S / 8;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,13 +61,13 @@ __global__ void im2col_kernel(const float* __restrict__ x, bf16_t* __restrict__ 
     int gy = y / P, py = y - gy * P;
     if (P % 8 == 0) {
         int gx = xs / P, px = xs - gx * P;
-        bf16_t* d = out + ((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px;
-        *(u32x4*)d = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        op_t* d = out + ((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px;
+        *(u32x4*)d = u32x4{pack_op2(v[0], v[1]), pack_op2(v[2], v[3]), pack_op2(v[4], v[5]), pack_op2(v[6], v[7])};
     } else {  // P = 14 (ViT-L/14): 8-pixel groups straddle patches
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int xx = xs + e, gx = xx / P, px = xx - gx * P;
-            out[((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px] = f32_to_bf16(v[e]);
+            out[((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px] = f32_to_op(v[e]);
         }
     }
 }
@@ -85,7 +85,7 @@ constexpr int LN_MAXC = 4;
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long row_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ y32, bf16_t* __restrict__ y16, int ld16,
+                                                     float* __restrict__ y32, op_t* __restrict__ y16, int ld16,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int D, float eps) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
             float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
             if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+            if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
         }
     }
 }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                     float* __restrict__ o32, bf16_t* __restrict__ o16, int rows, int D,
+                                                     float* __restrict__ o32, op_t* __restrict__ o16, int rows, int D,
                                                      long long xs, long long os, int stat_stride, int dres_T) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (o16) *(u32x2*)(o16 + (size_t)row * os + 4 * c) = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+            if (o16) *(u32x2*)(o16 + (size_t)row * os + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
         }
     }
 }
@@ -203,7 +203,7 @@ hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, con
     return hipGetLastError();
 }
 
-hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
+hipError_t launch_cast_f32_op(const float* src, op_t* dst, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     size_t blocks = (n / 8 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -212,18 +212,18 @@ hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_cast_rows_f32_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld, hipStream_t s) {
+hipError_t launch_cast_rows_f32_op(const float* src, int rows, int cols, op_t* dst, int ld, hipStream_t s) {
     size_t n = (size_t)rows * cols;
     hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst, ld);
     return hipGetLastError();
 }
 
-hipError_t launch_transpose_f32_bf16(const float* src, int R, int C, bf16_t* dst, int ld, hipStream_t s) {
+hipError_t launch_transpose_f32_op(const float* src, int R, int C, op_t* dst, int ld, hipStream_t s) {
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, R, C, dst, ld);
     return hipGetLastError();
 }
 
-hipError_t launch_im2col(const float* x, bf16_t* patches, int n, int S, int P, int Kp, hipStream_t s) {
+hipError_t launch_im2col(const float* x, op_t* patches, int n, int S, int P, int Kp, hipStream_t s) {
     if (S % 8) return hipErrorInvalidValue;
     size_t total = (size_t)n * 3 * S * (S / 8);
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, patches, n, S, P, Kp);
@@ -236,7 +236,7 @@ hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, 
 }
 
 hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta, float* y_f32,
-                            bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
+                            op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
                             hipStream_t s) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, y_f32, y_bf16,
@@ -245,7 +245,7 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 }
 
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                                const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16, int rows,
+                                const float* gamma, const float* dres, float* out_f32, op_t* out_bf16, int rows,
                                 int D, hipStream_t s, long long x_stride, long long o_stride, int stat_stride,
                                 int dres_T) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;

@@ -68,15 +68,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                 *(float4*)((float*)a.C + orow * a.ldc + n0) = make_float4(v0, v1, v2, v3);
             } else {
                 if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_op2(v0, v1), pack_op2(v2, v3)};
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
                 if constexpr (EPI == EPI_GELU_BWD) {
                     u32x2 t = *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
-                    v0 *= quick_gelu_grad_f(bf16lo(t[0])); v1 *= quick_gelu_grad_f(bf16hi(t[0]));
-                    v2 *= quick_gelu_grad_f(bf16lo(t[1])); v3 *= quick_gelu_grad_f(bf16hi(t[1]));
+                    v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
+                    v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
                 }
-                *(u32x2*)((bf16_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *(u32x2*)((op_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_op2(v0, v1), pack_op2(v2, v3)};
             }
         }
     }
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     const size_t koff = (size_t)blockIdx.y * nk * BK;
 
     // ---- per-thread DMA sources (row fixed for the whole K loop) ----
-    const bf16_t* asrc[NA];
-    const bf16_t* bsrc[NB];
+    const op_t* asrc[NA];
+    const op_t* bsrc[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
@@ -167,19 +167,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
             __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i - NA] + kt * BK),
                                              LDS_PTR(base + A_BYTES + ((i - NA) * NTHR + wave * 64) * 16), 16, 0, 0);
     };
-    auto load_frags = [&](const char* base, int s, bf16x8 (&xf)[MT], bf16x8 (&wf)[4]) {
+    auto load_frags = [&](const char* base, int s, opx8 (&xf)[MT], opx8 (&wf)[4]) {
         const int cA = ((4 * s + lg) ^ swA) << 4;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(base + offA[mt] + cA);
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const opx8*)(base + offA[mt] + cA);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(base + offW[nt] + cA);
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const opx8*)(base + offW[nt] + cA);
     };
-    auto mma = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[4]) {
+    auto mma = [&](const opx8 (&xf)[MT], const opx8 (&wf)[4]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = MFMA16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
     };
     if constexpr (STAGES == 2) {
         stage(0, 0);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
             __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
             const char* base = smem + (kt & 1) * STAGE;
             char* nxt = smem + ((kt + 1) & 1) * STAGE;
-            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            opx8 xf0[MT], wf0[4], xf1[MT], wf1[4];
             load_frags(base, 0, xf0, wf0);
             load_frags(base, 1, xf1, wf1);
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         {
             __syncthreads();
             const char* base = smem + ((nk - 1) & 1) * STAGE;
-            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            opx8 xf0[MT], wf0[4], xf1[MT], wf1[4];
             load_frags(base, 0, xf0, wf0);
             load_frags(base, 1, xf1, wf1);
             mma(xf0, wf0);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
             const char* base = smem + (kt % STAGES) * STAGE;
             char* nxt = smem + ((kt + STAGES - 1) % STAGES) * STAGE;
             const int kn = min(kt + STAGES - 1, nk - 1);
-            bf16x8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+            opx8 xf0[MT], wf0[4], xf1[MT], wf1[4];
             load_frags(base, 0, xf0, wf0);
             load_frags(base, 1, xf1, wf1);
 #pragma unroll
@@ -301,7 +301,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     }
     switch (epi) {
         case EPI_F32: return launch_v<EPI_F32>(a, s);
-        case EPI_BF16: return launch_v<EPI_BF16>(a, s);
+        case EPI_OP: return launch_v<EPI_OP>(a, s);
         case EPI_RESID_F32: return launch_v<EPI_RESID_F32>(a, s);
         case EPI_GELU: return launch_v<EPI_GELU>(a, s);
         case EPI_PATCH: return launch_v<EPI_PATCH>(a, s);

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* _
         a3 = fmaf(sm[k + 3], w[(size_t)(k + 3) * a.E], a3);
     }
     for (; k < a.K; ++k) a0 = fmaf(sm[k], w[(size_t)k * a.E], a0);
-    a.tmp_e[(size_t)v * a.E + e] = ((a0 + a1) + (a2 + a3)) * a.scale;
+    // TTL_GRAD_SCALE: fixed loss scale of the fp16 build (1 for bf16), removed again in wgrad_reduce_kernel
+    a.tmp_e[(size_t)v * a.E + e] = ((a0 + a1) + (a2 + a3)) * a.scale * TTL_GRAD_SCALE;
 }
 // grid (ceil(D/HB), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
 __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
@@ -319,7 +320,7 @@ hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, bf16_t* dh16, int n, hipStream_t s) {
+hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, op_t* dh16, int n, hipStream_t s) {
     hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
     hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
     hipError_t e = hipGetLastError();

@@ -8,21 +8,21 @@
 // on v_mfma_f32_16x16x32_bf16.  Requirements: K % 64 == 0, N % 128 == 0, lda/ldb % 8 == 0.
 enum GemmEpi {
     EPI_F32 = 0,       // C fp32 = acc (+ bias)
-    EPI_BF16 = 1,      // C bf16 = acc (+ bias)
+    EPI_OP = 1,      // C bf16 = acc (+ bias)
     EPI_RESID_F32 = 2, // C fp32 = resid + acc + bias
     EPI_GELU = 3,      // C bf16 = quick_gelu(acc + bias); C2 bf16 = acc + bias (if C2)
     EPI_PATCH = 4,     // C fp32 [(m/G2)*T + 1 + m%G2][n] = acc + pos[1 + m%G2][n]
     EPI_GELU_BWD = 5,  // C bf16 = acc * quick_gelu'(aux[m][n])
 };
 struct GemmArgs {
-    const bf16_t* A; int lda;
-    const bf16_t* B; int ldb;
+    const op_t* A; int lda;
+    const op_t* B; int ldb;
     int M, N, K;
     void* C; int ldc;
     const float* bias;            // [N] or null
     const float* resid; int ldr;  // EPI_RESID_F32
-    bf16_t* C2; int ldc2;         // EPI_GELU second output (pre-activation), may be null
-    const bf16_t* aux; int ldaux; // EPI_GELU_BWD: saved pre-activation u
+    op_t* C2; int ldc2;         // EPI_GELU second output (pre-activation), may be null
+    const op_t* aux; int ldaux; // EPI_GELU_BWD: saved pre-activation u
     const float* pos; int G2; int T; // EPI_PATCH
     float* ws; size_t ws_bytes;   // optional split-K workspace (small-M fp32-output calls)
     int splits;                   // internal: K slices of this launch (blockIdx.y)
@@ -31,29 +31,29 @@ struct GemmArgs {
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
-hipError_t launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+hipError_t launch_cast_f32_op(const float* src, op_t* dst, size_t n, hipStream_t s);
 // dst[r][c] = bf16(src[c][r])  (src [rows_src, cols_src] fp32 -> dst [cols_src, ld_dst] bf16)
-hipError_t launch_transpose_f32_bf16(const float* src, int rows_src, int cols_src, bf16_t* dst, int ld_dst,
+hipError_t launch_transpose_f32_op(const float* src, int rows_src, int cols_src, op_t* dst, int ld_dst,
                                      hipStream_t s);
 // dst rows of ld_dst elements: bf16(src[r][c]) for c < cols, untouched beyond
-hipError_t launch_cast_rows_f32_bf16(const float* src, int rows, int cols, bf16_t* dst, int ld_dst,
+hipError_t launch_cast_rows_f32_op(const float* src, int rows, int cols, op_t* dst, int ld_dst,
                                      hipStream_t s);
 // patches[(n*G+gy)*G+gx][c*P*P+py*P+px] = bf16(x[n][c][gy*P+py][gx*P+px]); zero pad to Kp
-hipError_t launch_im2col(const float* x, bf16_t* patches, int n, int S, int P, int Kp, hipStream_t s);
+hipError_t launch_im2col(const float* x, op_t* patches, int n, int S, int P, int Kp, hipStream_t s);
 // h[n*T + 0][:] = cls + pos[0]
 hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, int T, int D, hipStream_t s);
 // LayerNorm over rows of fp32 x [rows, D].  y_f32 (ld D) and/or y_bf16 (ld ld_bf16) outputs;
 // mean/rstd optional saves.  row_stride: distance (elements) between consecutive input rows
 // (T*D to pick CLS rows).
 hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta,
-                            float* y_f32, bf16_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
+                            float* y_f32, op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
                             int D, float eps, hipStream_t s);
 // dx = LN-backward(dy; x, mean, rstd, gamma); out_f32 = dres + dx; out_bf16 = bf16(out_f32)
 // x_stride / o_stride: row pitch (elements) of x and of dres/outputs (D when contiguous);
 // stat_stride: pitch of mean/rstd; dres_T > 0: dres is compact [rows/dres_T][D], non-zero only on
 // rows that are multiples of dres_T (CLS tokens)
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                                const float* gamma, const float* dres, float* out_f32, bf16_t* out_bf16,
+                                const float* gamma, const float* dres, float* out_f32, op_t* out_bf16,
                                 int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0,
                                 int stat_stride = 1, int dres_T = 0);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
@@ -62,15 +62,15 @@ hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, con
                                 const float* bias, float* out, int ldc, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
-hipError_t launch_attention_fwd(const bf16_t* qkv, int ld_qkv, bf16_t* out, int ld_out, float* lse, int n, int T,
+hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T,
                                 int H, hipStream_t s);
-hipError_t launch_attention_bwd(const bf16_t* qkv, int ld_qkv, const bf16_t* out, const bf16_t* dout, int ld_o,
-                                const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
+                                const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s);
 // Same gradients when d(out) is non-zero only for the CLS query of every view (the top layer):
 // dout_cls bf16 [n][H*64]; writes dense dq (zero rows for tokens > 0), dk, dv.
-hipError_t launch_attention_bwd_cls(const bf16_t* qkv, int ld_qkv, const bf16_t* out, int ld_o, const bf16_t* dout_cls,
-                                    const float* lse, bf16_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
+hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
+                                    const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s);
 
 // ---------------------------------------------------------------- head / loss / optimizer (head_loss.hip)
@@ -90,7 +90,7 @@ struct HeadArgs {
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s);
 // dlogits [n,K] -> gradient of the CLS rows, compact [n,D] fp32 + bf16 copy (all other rows of
 // the stream gradient are zero)
-hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls, bf16_t* dcls_bf16, int n, hipStream_t s);
+hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls, op_t* dcls_bf16, int n, hipStream_t s);
 
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
                                float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io,
@@ -106,16 +106,16 @@ hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, si
 //   wqkvT_ext [D][ldwt]: cols 3D..3D+r = A_q^T ; cols 3D+r..3D+2r = A_v^T
 //   a_cat [2r][D] = [A_q; A_v] ;  bT_cat [2r][D] = [B_q^T; B_v^T]
 hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av, const float* Bv, int D, int r,
-                               bf16_t* wqkv_ext, int ldw, bf16_t* wqkvT_ext, int ldwt, bf16_t* a_cat,
-                               bf16_t* bT_cat, hipStream_t s);
+                               op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat,
+                               op_t* bT_cat, hipStream_t s);
 // out[m][c] = bf16(scale * sum_k X[m][xoff(c) + k] * Wcat[c][k]),  c in [0,2r), k in [0,D)
 //   xoff(c) = (c < r) ? xoff_q : xoff_v   (lora_down: both 0; dU: dq at 0, dv at 2D)
-hipError_t launch_lora_skinny(const bf16_t* X, int ldx, int xoff_q, int xoff_v, const bf16_t* Wcat, int D, int r,
-                              float scale, bf16_t* out, int ldo, int M, hipStream_t s);
+hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, int r,
+                              float scale, op_t* out, int ldo, int M, hipStream_t s);
 // LoRA weight gradients of one layer from saved activations:
 //   dB_q = dq^T Us_q, dB_v = dv^T Us_v, dA_q = dU_q^T x1, dA_v = dU_v^T x1      (Us = s*x1*A^T)
 // x1ext [M][ldx]: cols 0..D = x1, cols D..D+2r = Us ; dqkv [M][ldd]: dq | dk | dv | dU_q dU_v
 // partial: fp32 scratch [nchunk][4][r][D]; grads written to gAq [r,D], gBq [D,r], gAv, gBv
-hipError_t launch_lora_wgrad(const bf16_t* x1ext, int ldx, const bf16_t* dqkv, int ldd, int M, int D, int r,
+hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r,
                              float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s);
 int lora_wgrad_chunks(int M);

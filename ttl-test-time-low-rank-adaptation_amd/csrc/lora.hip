@@ -14,14 +14,14 @@
 namespace {
 
 __global__ void refresh_kernel(const float* __restrict__ Aq, const float* __restrict__ Bq, const float* __restrict__ Av,
-                               const float* __restrict__ Bv, int D, int r, bf16_t* __restrict__ wext, int ldw,
-                               bf16_t* __restrict__ wtext, int ldwt, bf16_t* __restrict__ acat,
-                               bf16_t* __restrict__ btcat) {
+                               const float* __restrict__ Bv, int D, int r, op_t* __restrict__ wext, int ldw,
+                               op_t* __restrict__ wtext, int ldwt, op_t* __restrict__ acat,
+                               op_t* __restrict__ btcat) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D * r) return;
     {   // B side: i = n*r + j
         int n = i / r, j = i - n * r;
-        bf16_t bq = f32_to_bf16(Bq[i]), bv = f32_to_bf16(Bv[i]);
+        op_t bq = f32_to_op(Bq[i]), bv = f32_to_op(Bv[i]);
         wext[(size_t)n * ldw + D + j] = bq;
         wext[(size_t)(2 * D + n) * ldw + D + r + j] = bv;
         btcat[(size_t)j * D + n] = bq;
@@ -29,7 +29,7 @@ __global__ void refresh_kernel(const float* __restrict__ Aq, const float* __rest
     }
     {   // A side: i = j*D + d
         int j = i / D, d = i - j * D;
-        bf16_t aq = f32_to_bf16(Aq[i]), av = f32_to_bf16(Av[i]);
+        op_t aq = f32_to_op(Aq[i]), av = f32_to_op(Av[i]);
         acat[(size_t)j * D + d] = aq;
         acat[(size_t)(r + j) * D + d] = av;
         wtext[(size_t)d * ldwt + 3 * D + j] = aq;
@@ -41,34 +41,34 @@ __global__ void refresh_kernel(const float* __restrict__ Aq, const float* __rest
 // c of the result), B operand = X rows (output column = token) -> each lane ends with 4
 // consecutive result columns of one token: one 8-byte store.
 template <int NCG>
-__global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ X, int ldx, int xoff_q, int xoff_v,
-                                                     const bf16_t* __restrict__ W, int D, float scale,
-                                                     bf16_t* __restrict__ out, int ldo, int M) {
+__global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X, int ldx, int xoff_q, int xoff_v,
+                                                     const op_t* __restrict__ W, int D, float scale,
+                                                     op_t* __restrict__ out, int ldo, int M) {
     const int lane = threadIdx.x & 63;
     const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (m0 >= M) return;
     const int li = lane & 15, lg = lane >> 4;
     const int row = min(m0 + li, M - 1);
-    const bf16_t* xq = X + (size_t)row * ldx + xoff_q + 8 * lg;
-    const bf16_t* xv = X + (size_t)row * ldx + xoff_v + 8 * lg;
+    const op_t* xq = X + (size_t)row * ldx + xoff_q + 8 * lg;
+    const op_t* xv = X + (size_t)row * ldx + xoff_v + 8 * lg;
     const bool same = (xoff_q == xoff_v);
     f32x4 acc[NCG];
 #pragma unroll
     for (int c = 0; c < NCG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < D; k += 32) {
-        bf16x8 fq = *(const bf16x8*)(xq + k);
-        bf16x8 fv = same ? fq : *(const bf16x8*)(xv + k);
+        opx8 fq = *(const opx8*)(xq + k);
+        opx8 fv = same ? fq : *(const opx8*)(xv + k);
 #pragma unroll
         for (int c = 0; c < NCG; ++c) {
-            bf16x8 w = *(const bf16x8*)(W + (size_t)(c * 16 + li) * D + k + 8 * lg);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, (c < NCG / 2) ? fq : fv, acc[c], 0, 0, 0);
+            opx8 w = *(const opx8*)(W + (size_t)(c * 16 + li) * D + k + 8 * lg);
+            acc[c] = MFMA16(w, (c < NCG / 2) ? fq : fv, acc[c], 0, 0, 0);
         }
     }
     if (m0 + li < M) {
 #pragma unroll
         for (int c = 0; c < NCG; ++c)
             *(u32x2*)(out + (size_t)(m0 + li) * ldo + c * 16 + 4 * lg) =
-                u32x2{pack_bf16x2(acc[c][0] * scale, acc[c][1] * scale), pack_bf16x2(acc[c][2] * scale, acc[c][3] * scale)};
+                u32x2{pack_op2(acc[c][0] * scale, acc[c][1] * scale), pack_op2(acc[c][2] * scale, acc[c][3] * scale)};
     }
 }
 
@@ -79,7 +79,7 @@ constexpr int WG_BN = 128;   // result columns per block
 __device__ __forceinline__ int wg_u(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <int R>
-__global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x1ext, int ldx, const bf16_t* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void wgrad_kernel(const op_t* __restrict__ x1ext, int ldx, const op_t* __restrict__ dqkv,
                                                     int ldd, int M, int D, float* __restrict__ partial, int nch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sG = smem;                       // [256][128] bf16, 256-B rows, 16-B chunk c at c ^ (u(row) << 1)
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x
     const int ch = blockIdx.x, cb = blockIdx.y, prod = blockIdx.z;
     const int m0 = ch * WG_CH, n0 = cb * WG_BN;
     // operands of this product
-    const bf16_t* S; int lds_; const bf16_t* G; int ldg;
+    const op_t* S; int lds_; const op_t* G; int ldg;
     if (prod == 0)      { S = x1ext + D;           lds_ = ldx; G = dqkv;          ldg = ldd; }  // dB_q^T = Us_q^T dq
     else if (prod == 1) { S = x1ext + D + R;       lds_ = ldx; G = dqkv + 2 * D;  ldg = ldd; }  // dB_v^T = Us_v^T dv
     else if (prod == 2) { S = dqkv + 3 * D;        lds_ = ldd; G = x1ext;         ldg = ldx; }  // dA_q = dU_q^T x1
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x
 #pragma unroll 2
     for (int ks = 0; ks < WG_CH / 32; ++ks) {
         const int rlo = 32 * ks + 8 * lg + tq, rhi = rlo + 4;
-        bf16x8 sf[R / 16], gf[2];
+        opx8 sf[R / 16], gf[2];
 #pragma unroll
         for (int a = 0; a < R / 16; ++a) {
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + rlo * (R * 2) + (a * 16 + 4 * tp) * 2));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + rhi * (R * 2) + (a * 16 + 4 * tp) * 2));
             s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            sf[a] = __builtin_bit_cast(bf16x8, v);
+            sf[a] = __builtin_bit_cast(opx8, v);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -130,12 +130,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + rlo * 256 + ((slot ^ (wg_u(rlo) << 2)) << 3)));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + rhi * 256 + ((slot ^ (wg_u(rhi) << 2)) << 3)));
             s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            gf[b] = __builtin_bit_cast(bf16x8, v);
+            gf[b] = __builtin_bit_cast(opx8, v);
         }
 #pragma unroll
         for (int a = 0; a < R / 16; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[a], gf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(sf[a], gf[b], acc[a][b], 0, 0, 0);
     }
     float* po = partial + ((size_t)prod * nch + ch) * R * D;
 #pragma unroll
@@ -155,6 +155,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, 
     const float* p = partial + (size_t)prod * nch * r * D + i;
     float s = 0.f;
     for (int c = 0; c < nch; ++c) s += p[(size_t)c * r * D];
+    s *= (1.0f / TTL_GRAD_SCALE);   // undo the backward's loss scale (fp16 build; 1 for bf16)
     int j = i / D, d = i - j * D;
     if (prod == 0) gBq[(size_t)d * r + j] = s;
     else if (prod == 1) gBv[(size_t)d * r + j] = s;
@@ -165,15 +166,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, 
 }  // namespace
 
 hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av, const float* Bv, int D, int r,
-                               bf16_t* wqkv_ext, int ldw, bf16_t* wqkvT_ext, int ldwt, bf16_t* a_cat, bf16_t* bT_cat,
+                               op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat, op_t* bT_cat,
                                hipStream_t s) {
     hipLaunchKernelGGL(refresh_kernel, dim3((D * r + 255) / 256), dim3(256), 0, s, Aq, Bq, Av, Bv, D, r, wqkv_ext, ldw,
                        wqkvT_ext, ldwt, a_cat, bT_cat);
     return hipGetLastError();
 }
 
-hipError_t launch_lora_skinny(const bf16_t* X, int ldx, int xoff_q, int xoff_v, const bf16_t* Wcat, int D, int r,
-                              float scale, bf16_t* out, int ldo, int M, hipStream_t s) {
+hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, int r,
+                              float scale, op_t* out, int ldo, int M, hipStream_t s) {
     if (D % 32) return hipErrorInvalidValue;
     dim3 grid((M + 63) / 64), block(256);
     if (r == 16) hipLaunchKernelGGL((skinny_kernel<2>), grid, block, 0, s, X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M);
@@ -184,7 +185,7 @@ hipError_t launch_lora_skinny(const bf16_t* X, int ldx, int xoff_q, int xoff_v, 
 
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
 
-hipError_t launch_lora_wgrad(const bf16_t* x1ext, int ldx, const bf16_t* dqkv, int ldd, int M, int D, int r, float* partial,
+hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r, float* partial,
                              float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s) {
     if (D % WG_BN) return hipErrorInvalidValue;
     const int nch = lora_wgrad_chunks(M);

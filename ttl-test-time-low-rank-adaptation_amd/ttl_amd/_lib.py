@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttl_hip.so")
+LIB_PATH = os.path.join(_HERE, "libttl_hip.so")            # bf16 operands (default; BASELINE north_star)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libttl_hip_fp16.so")}   # same ABI, operand dtype differs
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ttl_hip.h"))
 
 TTL_SEL_LE_THRESH = 0
@@ -43,6 +44,7 @@ _P, _I, _F, _D, _Z = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 SIGNATURES = {
     "ttl_last_error": (C.c_char_p, []),
     "ttl_version": (C.c_char_p, []),
+    "ttl_operand_dtype": (C.c_char_p, []),
     "ttl_workspace_bytes": (_Z, [C.POINTER(ttl_config)]),
     "ttl_ctx_create": (_I, [C.POINTER(ttl_config), C.POINTER(_P)]),
     "ttl_ctx_destroy": (None, [_P]),
@@ -57,9 +59,9 @@ SIGNATURES = {
     "ttl_adamw_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
     "ttl_lora_reset": (_I, [_P, _P, _P, _P, _Z, _P]),
     "ttl_episode": (_I, [_P, C.POINTER(ttl_episode_args), _P]),
-    "ttl_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ttl_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ttl_layernorm_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
-    "ttl_cast_f32_bf16": (_I, [_P, _P, _Z, _P]),
+    "ttl_cast_f32_operand": (_I, [_P, _P, _Z, _P]),
     "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ttl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),
@@ -75,14 +77,17 @@ def header_symbols(path=HEADER_PATH):
     return sorted(set(re.findall(r"\b(ttl_[a-z0-9_]+)\s*\(", txt)))
 
 
-_lib = None
+_libs = {}
 
 
-def load(path=LIB_PATH):
-    """dlopen the library and attach signatures.  Raises TtlError if anything is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(precision="bf16"):
+    """dlopen the library built for ``precision`` operands and attach signatures.
+    Raises TtlError if the file or any declared symbol is missing (no fallback)."""
+    if precision in _libs:
+        return _libs[precision]
+    if precision not in LIB_PATHS:
+        raise TtlError(f"unknown operand precision {precision!r}; built variants: {sorted(LIB_PATHS)}")
+    path = LIB_PATHS[precision]
     if not os.path.exists(path):
         raise TtlError(f"{path} not found: the HIP extension is not built "
                        f"(run `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}`); there is no CPU fallback")
@@ -90,7 +95,7 @@ def load(path=LIB_PATH):
         import torch  # noqa: F401  — load torch's libamdhip64 first so both share one HIP runtime
     except Exception:  # pragma: no cover
         pass
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)   # both variants export the same names: keep them local
     missing = []
     for name, (res, args) in SIGNATURES.items():
         try:
@@ -102,11 +107,14 @@ def load(path=LIB_PATH):
         fn.argtypes = args
     if missing:
         raise TtlError(f"{path} does not export: {', '.join(missing)}")
-    _lib = lib
+    got = lib.ttl_operand_dtype().decode()
+    if got != precision:
+        raise TtlError(f"{path} was built for {got} operands, expected {precision}")
+    _libs[precision] = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().ttl_last_error()
+        msg = (lib or load()).ttl_last_error()
         raise TtlError(f"libttl_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -247,7 +247,7 @@ class ClipTestTimeTuning(nn.Module):
 
     def __init__(self, device, classnames, batch_size, criterion='cosine', arch="ViT-B/16", n_ctx=16, ctx_init=None,
                  ctx_position='end', learned_cls=False, layer_range=[9, 11], init_method=None, lora_encoder='text',
-                 rank=16, max_views=64, max_classes=1000, weight_seed=0):
+                 rank=16, max_views=64, max_classes=1000, weight_seed=0, precision="bf16"):
         super().__init__()
         if lora_encoder != 'image':
             raise NotImplementedError(f"lora_encoder={lora_encoder!r}: only the image-LoRA path is built "
@@ -258,6 +258,7 @@ class ClipTestTimeTuning(nn.Module):
         self.cfg = cfg = cfg.replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1])
         self.layer_range = list(layer_range)
         self.criterion = criterion
+        self.precision = precision   # MFMA operand dtype: "bf16" (default) or "fp16" (reference's autocast dtype)
         self.max_views = max(int(batch_size or 0), int(max_views))
         self.max_classes = max(int(max_classes), len(classnames))
         clip_model, vis_state, tokenizer = _build_clip(cfg, os.environ.get(CLIP_WEIGHTS_ENV), weight_seed)
@@ -298,7 +299,7 @@ class ClipTestTimeTuning(nn.Module):
         if self.engine is None or self.engine.device != dev:
             if self.engine is not None:
                 self.engine.close()
-            self.engine = TTLEngine(self.cfg, self.max_views, self.max_classes, dev)
+            self.engine = TTLEngine(self.cfg, self.max_views, self.max_classes, dev, self.precision)
             self.engine.load_weights(self._vision_state)
             self._flat = None
             self._text_dirty = True

@@ -26,8 +26,10 @@ def _stream():
 class TTLEngine:
     """Owns the HIP context (frozen bf16 weights + activation arena) of one image tower."""
 
-    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device):
-        self.lib = _lib.load()
+    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device, precision: str = "bf16"):
+        """precision: MFMA operand dtype — "bf16" (default) or "fp16" (the reference's autocast dtype)."""
+        self.precision = precision
+        self.lib = _lib.load(precision)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -41,12 +43,15 @@ class TTLEngine:
         self._ccfg = c
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
+            self._check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
         self._h = h
         self.n_lora = (cfg.layer_hi - cfg.layer_lo + 1) * 4 * cfg.rank * cfg.width
         self.grads = torch.zeros(self.n_lora, dtype=torch.float32, device=self.device)
         self._params = None
         self._keep = []
+
+    def _check(self, rc):
+        _lib.check(rc, self.lib)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -79,20 +84,20 @@ class TTLEngine:
                 else:
                     a = np.ascontiguousarray(a, dtype=np.float32)
                     ptr, cnt = a.ctypes.data_as(C.c_void_p), a.size
-                _lib.check(self.lib.ttl_load_weight(self._h, name.encode(), ptr, cnt))
-            _lib.check(self.lib.ttl_weights_ready(self._h))
+                self._check(self.lib.ttl_load_weight(self._h, name.encode(), ptr, cnt))
+            self._check(self.lib.ttl_weights_ready(self._h))
 
     def set_text_features(self, tfeat: torch.Tensor, logit_scale_exp: float):
         """tfeat: [K,E] unit-norm class embeddings (clip/custom_clip.py:651-663)."""
         t = tfeat.detach().to(device=self.device, dtype=torch.float32).contiguous()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_set_text_features(self._h, _ptr(t), t.shape[0], float(logit_scale_exp), _stream()))
+            self._check(self.lib.ttl_set_text_features(self._h, _ptr(t), t.shape[0], float(logit_scale_exp), _stream()))
         self.n_classes = int(t.shape[0])
 
     def bind_lora(self, params_flat: torch.Tensor):
         assert params_flat.numel() == self.n_lora and params_flat.dtype == torch.float32
         self._params = params_flat
-        _lib.check(self.lib.ttl_bind_lora(self._h, _ptr(params_flat), _ptr(self.grads), self.n_lora))
+        self._check(self.lib.ttl_bind_lora(self._h, _ptr(params_flat), _ptr(self.grads), self.n_lora))
 
     # ------------------------------------------------------------------ hot path
     def forward(self, x: torch.Tensor, save: bool = False, want_features: bool = False):
@@ -101,13 +106,13 @@ class TTLEngine:
         logits = torch.empty((n, self.n_classes), dtype=torch.float32, device=self.device)
         feats = torch.empty((n, self.cfg.embed), dtype=torch.float32, device=self.device) if want_features else None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_vit_forward(self._h, _ptr(x), n, 1 if save else 0, _ptr(logits), _ptr(feats), _stream()))
+            self._check(self.lib.ttl_vit_forward(self._h, _ptr(x), n, 1 if save else 0, _ptr(logits), _ptr(feats), _stream()))
         return (logits, feats) if want_features else logits
 
     def backward(self, dlogits: torch.Tensor):
         d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
+            self._check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
         return self.grads
 
     def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0):
@@ -121,7 +126,7 @@ class TTLEngine:
                    dlogits=torch.empty_like(z))
         th = math.log(1000.0) if thresh is None else thresh
         with torch.cuda.device(dev):
-            _lib.check(self.lib.ttl_entropy_select_loss(_ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
+            self._check(self.lib.ttl_entropy_select_loss(_ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
                                                         float(reweight), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
                                                         _ptr(out["loss"]), _ptr(out["dlogits"]), _stream()))
         return out
@@ -136,7 +141,7 @@ class TTLEngine:
                    n=n if reuse else torch.zeros(1, dtype=torch.int32, device=dev),
                    loss=torch.zeros(1, device=dev), dlogits=torch.empty_like(z))
         with torch.cuda.device(dev):
-            _lib.check(self.lib.ttl_tpt_select_loss(_ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
+            self._check(self.lib.ttl_tpt_select_loss(_ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
                                                     _ptr(out["idx"]), _ptr(out["n"]), _ptr(out["loss"]),
                                                     _ptr(out["dlogits"]), _stream()))
         return out
@@ -144,12 +149,12 @@ class TTLEngine:
     def adamw_step(self, params, grads, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                    n_selected=None):
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
+            self._check(self.lib.ttl_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
                                                betas[1], eps, weight_decay, int(step), _ptr(n_selected), _stream()))
 
     def lora_reset(self, params, snapshot, m=None, v=None):
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_lora_reset(_ptr(params), _ptr(snapshot), _ptr(m), _ptr(v), params.numel(), _stream()))
+            self._check(self.lib.ttl_lora_reset(_ptr(params), _ptr(snapshot), _ptr(m), _ptr(v), params.numel(), _stream()))
 
     def episode(self, x, snapshot, m, v, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH, rho=0.1,
                 thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
@@ -171,23 +176,23 @@ class TTLEngine:
         a.logits0_out = l0.data_ptr() if want_logits0 else None
         a.logits1_out = l1.data_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
+            self._check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
         return (l1, l0) if want_logits0 else l1
 
     # ------------------------------------------------------------------ debugging / measurement
     def debug_copy(self, name, layer, shape, dtype=np.float32):
         a = np.empty(shape, dtype=dtype)
-        _lib.check(self.lib.ttl_debug_copy(self._h, name.encode(), int(layer), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        self._check(self.lib.ttl_debug_copy(self._h, name.encode(), int(layer), a.ctypes.data_as(C.c_void_p), a.nbytes))
         return a
 
     def profile_enable(self, on=True):
-        _lib.check(self.lib.ttl_profile_enable(self._h, 1 if on else 0))
+        self._check(self.lib.ttl_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self):
         ms = (C.c_double * _lib.TTL_NCLASS)()
         cnt = (C.c_longlong * _lib.TTL_NCLASS)()
         fl = C.c_double()
-        _lib.check(self.lib.ttl_profile_read(self._h, ms, cnt, C.byref(fl)))
+        self._check(self.lib.ttl_profile_read(self._h, ms, cnt, C.byref(fl)))
         return ({k: ms[i] for i, k in enumerate(_lib.PROFILE_CLASSES)},
                 {k: cnt[i] for i, k in enumerate(_lib.PROFILE_CLASSES)}, fl.value)
 
