@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
+    ap.add_argument("--streams", type=int, default=2, help="independent episodes in flight per GPU (HIP streams)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="MFMA operand dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -102,27 +104,24 @@ def main():
     from ttl_amd.config import get_config
     from ttl_amd.engine import TTLEngine
 
+    from ttl_amd.driver import EpisodePipeline
     cfg = get_config(a.arch).replace(rank=a.rank)
-    eng = TTLEngine(cfg, a.views, a.classes, dev)
-    eng.load_weights(synth.vision_weights(cfg, 0))
-    eng.set_text_features(torch.from_numpy(synth.text_features(a.classes, cfg.embed)), 100.0)
     lora = synth.lora_init(cfg, 0)
     names = [f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight"
              for i in range(cfg.layer_lo, cfg.layer_hi + 1) for pj in ("q_proj", "v_proj") for ab in ("A", "B")]
-    flat = torch.cat([torch.from_numpy(lora[k]).reshape(-1) for k in names]).to(dev).contiguous()
-    eng.bind_lora(flat)
-    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    pipe = EpisodePipeline(cfg, synth.vision_weights(cfg, 0), names, lora,
+                           torch.from_numpy(synth.text_features(a.classes, cfg.embed)), 100.0, dev,
+                           n_streams=a.streams, max_views=a.views, precision=a.precision)
+    eng = pipe.slots[0]["eng"]
     # synthetic inputs of the workload's shape, already resident in HBM (data: synthetic)
     pool = [torch.from_numpy(synth.views(cfg, a.views, 1000 + rank * a.pool + j)).to(dev) for j in range(a.pool)]
-    labels = torch.arange(a.pool, device=dev) % a.classes
-    hits = torch.zeros(3, dtype=torch.int64, device=dev)
+    labels = [torch.tensor([(7 * j) % a.classes], device=dev) for j in range(a.pool)]
 
     def step(i):
-        l1 = eng.episode(pool[i % a.pool], snap, m, v, n_updates=a.updates)
-        hits[0] += (l1.argmax(1) == labels[i % a.pool]).sum()
-        hits[2] += 1
+        pipe.submit(pool[i % a.pool], target=labels[i % a.pool], n_updates=a.updates)
 
     def fence():
+        pipe.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -137,24 +136,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    hits = pipe.totals()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(hits, op=dist.ReduceOp.SUM)      # C1: accuracy accumulator
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM)      # C1: accuracy accumulator (the path's only collective)
     T = float(tmax.item())
 
     # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): HIP events on the launch stream
     roof = None
     if rank == 0:
+        # one stream only: kernels of a second in-flight episode would share the CUs and inflate durations
         eng.profile_enable(True)
         nprof = 5
+        sl = pipe.slots[0]
         for i in range(nprof):
-            step(i)
+            with torch.cuda.stream(sl["stream"]):
+                eng.episode(pool[i % a.pool], sl["snap"], sl["m"], sl["v"], n_updates=a.updates)
+        sl["stream"].synchronize()
         ms, cnt, gflops = eng.profile_read()
         eng.profile_enable(False)
         ach = gflops / (ms["gemm"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_kernel<128,*> (all epilogues)",
+                "kernel": "gemm_kernel<160,2,2,2,EPI,false> + <128,2,2,4,EPI,true> (all GEMM launches of an episode, single stream)",
                 "flops_per_launch": round(gflops / max(cnt["gemm"], 1)),
                 "avg_launch_us": round(1e3 * ms["gemm"] / max(cnt["gemm"], 1), 2),
                 "launches_per_image": cnt["gemm"] // nprof,
@@ -166,22 +170,23 @@ def main():
             "metric": "test images/sec (64-view TTA, 1 step), CLIP ViT-B/16 r=16",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * T / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{cfg.name} r={cfg.rank}, {a.views} views, {a.updates} TTA step, K={a.classes} "
                                    f"(ImageNet-A shape), layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
                                    f"1-view inference; views pre-staged in HBM; {a.steps} images/rank",
                        "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates,
-                       "parallelism": f"image-sharded x{world}"},
+                       "streams_per_gpu": a.streams, "parallelism": f"image-sharded x{world}, {a.streams} episodes in flight per GPU"},
             "tflop_per_image": round(flops / 1e12, 3),
             "whole_path_tflops_per_gpu": round(flops * value / world / 1e12, 1),
             "whole_path_frac_of_bf16_peak": round(flops * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "top1_self_consistency": {"hits": int(hits[0].item()), "count": int(hits[2].item())},
+            "accuracy_accumulator": {"top1_hits": int(hits[0]), "top5_hits": int(hits[1]), "images": int(hits[2]),
+                                     "note": "synthetic labels: exercises the sharded accumulator + all-reduce, not a quality number"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.classes)
         print(json.dumps(out), flush=True)
-    eng.close()
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -68,3 +68,61 @@ class EpisodeRunner:
         """views [N,3,S,S] (view 0 = the un-augmented image) -> logits [1,K] with adapted weights."""
         m = self.model
         return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
+
+
+class EpisodePipeline:
+    """S independent episodes in flight on S HIP streams of ONE GPU.
+
+    Episodes of different test images share nothing but the frozen weights (ttl.py:338-344 resets
+    LoRA + Adam state per image), so the launch tails, small kernels and HBM-bound phases of one
+    image overlap with the MFMA-bound phases of another: +18 % images/s at S = 2 on MI355X
+    (tools/two_stream_bench.py).  Every slot owns a context (its activation arena), its LoRA /
+    gradient / Adam buffers and a stream; results are identical to running the slots one by one.
+    """
+
+    def __init__(self, cfg, weights, lora_names, lora_init, text_features, logit_scale_exp, device, n_streams=2,
+                 max_views=64, precision="bf16"):
+        from .engine import TTLEngine
+        self.slots = []
+        dev = torch.device(device)
+        for _ in range(max(1, int(n_streams))):
+            eng = TTLEngine(cfg, max_views, text_features.shape[0], dev, precision)
+            eng.load_weights(weights)
+            eng.set_text_features(text_features, logit_scale_exp)
+            flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in lora_names]).to(dev).contiguous()
+            eng.bind_lora(flat)
+            self.slots.append(dict(eng=eng, flat=flat, snap=flat.clone(), m=torch.zeros_like(flat), v=torch.zeros_like(flat),
+                                   stream=torch.cuda.Stream(device=dev),
+                                   acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
+        self._next = 0
+        torch.cuda.synchronize(dev)
+
+    def submit(self, views, target=None, **episode_kw):
+        """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K].
+        With ``target`` (device int64 [1]) the slot's [hits1, hits5, count] accumulator is updated on
+        the same stream (no host sync).  The caller must not overwrite ``views`` until the slot's
+        stream has caught up."""
+        sl = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        sl["stream"].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sl["stream"]):
+            out = sl["eng"].episode(views, sl["snap"], sl["m"], sl["v"], **episode_kw)
+            if target is not None:
+                h1, h5 = topk_hits(out, target)
+                sl["acc"][0] += h1
+                sl["acc"][1] += h5
+                sl["acc"][2] += 1
+        return out
+
+    def synchronize(self):
+        for sl in self.slots:
+            sl["stream"].synchronize()
+
+    def totals(self):
+        """Sum of the per-slot accuracy accumulators (device int64 [3]) after draining the streams."""
+        self.synchronize()
+        return torch.stack([sl["acc"] for sl in self.slots]).sum(0)
+
+    def close(self):
+        for sl in self.slots:
+            sl["eng"].close()
