@@ -102,34 +102,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
     __syncthreads();
 
     const int nqb = (T + 31) >> 5;
+    constexpr float C2 = SCALE * 1.4426950408889634f;   // softmax in base 2: p = exp2(s*C2 - m*C2)
     for (int qb = wave; qb < nqb; qb += 4) {
         const int qrow = min(qb * 32 + (lane & 31), T - 1);
         opx8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = global_frag(qg, ld, qrow, ks, lane);
         f32x16 st[NKT];
-        float mx = -INFINITY;
+        float mx = -INFINITY;   // max of the RAW scores (the scale is positive: same arg-max)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x16 a = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 a = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+            if (32 * kt + 32 > T) {   // wave-uniform: only the tile(s) holding keys >= T pay for the mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (32 * kt + acc_row(r, lane) < T) ? a[r] * SCALE : -INFINITY;
-                a[r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kt + acc_row(r, lane) >= T) a[r] = -INFINITY;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, a[r]);
             st[kt] = a;
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * C2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __expf(st[kt][r] - mx);
+                float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], C2, -mc));
                 st[kt][r] = p;
                 sum += p;
             }
@@ -142,13 +145,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
                 opx8 pf = acc_frag(st[kt], s);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = MFMA32(tr_frag(sV, 32 * kt + 16 * s, 32 * dt, lane), pf,
-                                                                    o[dt], 0, 0, 0);
+                    o[dt] = MFMA32(tr_frag(sV, 32 * kt + 16 * s, 32 * dt, lane), pf, o[dt], 0, 0, 0);
             }
         const int q = qb * 32 + (lane & 31);
         if (q < T) {
             store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / sum, lane);
-            if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = mx + __logf(sum);
+            if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = mx * SCALE + __logf(sum);
         }
     }
 }
