@@ -115,33 +115,35 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     const int nk = a.K / BK / a.splits;
     const size_t koff = (size_t)blockIdx.y * nk * BK;
 
-    // ---- per-thread DMA sources (row fixed for the whole K loop) ----
-    const op_t* asrc[NA];
-    const op_t* bsrc[NB];
+    // ---- per-thread DMA sources (row fixed for the whole K loop): 32-bit lane offsets from a
+    // wave-uniform base, so stepping K is scalar arithmetic (global_load_lds saddr + voffset form)
+    uint32_t aoff[NA], boff[NB];
+    const char* abase = (const char*)a.A + koff * sizeof(op_t);
+    const char* bbase = (const char*)a.B + koff * sizeof(op_t);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int gr = min(row0 + r, M - 1);
-        asrc[i] = a.A + (size_t)gr * a.lda + c * 8 + koff;
+        aoff[i] = (uint32_t)(((size_t)gr * a.lda + c * 8) * sizeof(op_t));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int n = (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);  // physical LDS row r holds this output column
-        bsrc[i] = a.B + (size_t)(col0 + n) * a.ldb + c * 8 + koff;
+        boff[i] = (uint32_t)(((size_t)(col0 + n) * a.ldb + c * 8) * sizeof(op_t));
     }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
+        const char* ak = abase + (size_t)kt * (BK * sizeof(op_t));
+        const char* bk = bbase + (size_t)kt * (BK * sizeof(op_t));
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + (i * NTHR + wave * 64) * 16),
-                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ak + aoff[i]), LDS_PTR(base + (i * NTHR + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i] + kt * BK),
-                                             LDS_PTR(base + A_BYTES + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bk + boff[i]), LDS_PTR(base + A_BYTES + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     };
 
     // ---- per-lane fragment addresses ----
@@ -162,9 +164,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     constexpr int NP0 = (NP + 1) / 2;      // issued under the first 32-deep half, the rest under the second
     auto stage_piece = [&](int i, int kt, char* base) {
         if (i < NA)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(abase + (size_t)kt * (BK * sizeof(op_t)) + aoff[i]),
+                                             LDS_PTR(base + (i * NTHR + wave * 64) * 16), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i - NA] + kt * BK),
+            __builtin_amdgcn_global_load_lds(GLB_PTR(bbase + (size_t)kt * (BK * sizeof(op_t)) + boff[i - NA]),
                                              LDS_PTR(base + A_BYTES + ((i - NA) * NTHR + wave * 64) * 16), 16, 0, 0);
     };
     auto load_frags = [&](const char* base, int s, opx8 (&xf)[MT], opx8 (&wf)[4]) {
