@@ -155,7 +155,7 @@ void set_geometry(ttl_ctx* c, const ttl_config* k) {
     c->ldw = c->D + 64;        // wqkv rows
     c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
     c->nT = k->layer_hi - k->layer_lo + 1;
-    c->Mmax = round_up(k->max_views * c->T, 320);  // padded: the big GEMM tiles store whole row tiles unguarded
+    c->Mmax = round_up(k->max_views * c->T, 1280);  // padded: the big GEMM tiles store whole row tiles unguarded
     c->scaling = k->lora_alpha / (float)k->rank;
 }
 

@@ -262,6 +262,8 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 //   320x128x64, 8 waves, 1 block/CU .............................. 4.35 ms (nothing overlaps its prologue/epilogue)
 //   160x128x32, 2/3/4-stage LDS ring, counted vmcnt, register
 //   double-buffered fragments, 2-3 blocks/CU ..................... 4.37-4.48 ms (twice the barriers per K)
+//   256x128x64, 8 waves in two groups one barrier apart (one loads
+//   fragments + issues DMA while the other issues MFMAs), 3 stages  +5% on the N >= 2304 shapes, +15% overall
 // M = 12608 gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 /
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
