@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
                                                            int ldo, const op_t* __restrict__ dout_cls,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv, int ldd,
                                                            int T, int H) {
-    __shared__ float sq[64], sdo[64], sds[320], sred[4][64];
+    // 8 lanes per key, lane c of the group owns head-dim chunk c (8 values = one 16-B access): every
+    // load / store instruction touches whole 128-B rows
+    __shared__ float sq[64], sdo[64], sred[32][64];
     __shared__ float sdelta;
     const int tid = threadIdx.x;
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
@@ -325,53 +327,54 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
         sq[tid] = op_to_f32(base[tid]);
         float d = op_to_f32(dout_cls[(size_t)img * D + head * 64 + tid]);
         sdo[tid] = d;
-        float prod = d * op_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]);
-        prod = wave_sum(prod);
+        float prod = wave_sum(d * op_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]));
         if (tid == 0) sdelta = prod;
     }
     __syncthreads();
     const float l0 = lse[((size_t)img * H + head) * T];
     const float delta = sdelta;
-    for (int j = tid; j < T; j += 256) {
-        const op_t* kr = base + (size_t)j * ld + D;
-        const op_t* vr = base + (size_t)j * ld + 2 * D;
+    const int c = tid & 7, grp = tid >> 3;            // 32 key groups per pass
+    float qc[8], dc[8], dq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qc[e] = sq[8 * c + e]; dc[e] = sdo[8 * c + e]; dq[e] = 0.f; }
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        const int j = j0 + grp;
+        const bool ok = j < T;
+        const int jr = ok ? j : T - 1;
+        opx8 kf = *(const opx8*)(base + (size_t)jr * ld + D + 8 * c);
+        opx8 vf = *(const opx8*)(base + (size_t)jr * ld + 2 * D + 8 * c);
         float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            opx8 kf = *(const opx8*)(kr + 8 * c), vf = *(const opx8*)(vr + 8 * c);
+        for (int e = 0; e < 8; ++e) { s = fmaf(qc[e], (float)kf[e], s); dp = fmaf(dc[e], (float)vf[e], dp); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s = fmaf(sq[8 * c + e], (float)kf[e], s); dp = fmaf(sdo[8 * c + e], (float)vf[e], dp); }
-        }
+        for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); dp += __shfl_xor(dp, o, 64); }
         const float p = __expf(s * SCALE - l0);
-        // the MFMA path rounds P and dS to bf16 before the second products; keep the same points
+        // the MFMA path rounds P and dS to the operand type before the second products; same points here
         const float pb = op_to_f32(f32_to_op(p));
-        const float ds = op_to_f32(f32_to_op(p * (dp - delta)));
-        sds[j] = ds;
-        op_t* o = dqkv + (size_t)(img * T + j) * ldd + head * 64;
+        const float ds = ok ? op_to_f32(f32_to_op(p * (dp - delta))) : 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            u32x4 dv, dk, z = {0u, 0u, 0u, 0u};
+        for (int e = 0; e < 8; ++e) dq[e] = fmaf(ds, (float)kf[e], dq[e]);
+        if (ok) {
+            op_t* o = dqkv + (size_t)(img * T + j) * ldd + head * 64 + 8 * c;
+            u32x4 dv, dk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dv[e] = pack_op2(pb * sdo[8 * c + 2 * e], pb * sdo[8 * c + 2 * e + 1]);
-                dk[e] = pack_op2(ds * sq[8 * c + 2 * e] * SCALE, ds * sq[8 * c + 2 * e + 1] * SCALE);
+                dv[e] = pack_op2(pb * dc[2 * e], pb * dc[2 * e + 1]);
+                dk[e] = pack_op2(ds * qc[2 * e] * SCALE, ds * qc[2 * e + 1] * SCALE);
             }
-            *(u32x4*)(o + 2 * D + 8 * c) = dv;
-            if (NEED_DK) *(u32x4*)(o + D + 8 * c) = dk;
-            if (j > 0) *(u32x4*)(o + 8 * c) = z;
+            *(u32x4*)(o + 2 * D) = dv;
+            if (NEED_DK) *(u32x4*)(o + D) = dk;
+            if (j > 0) *(u32x4*)o = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    __syncthreads();
-    // dq_0[d] = sum_j ds_j k_j[d] / 8 : 4 waves split the keys, lane = d
-    {
-        const int d = tid & 63, w = tid >> 6;
-        float acc = 0.f;
-        for (int j = w; j < T; j += 4) acc = fmaf(sds[j], op_to_f32(base[(size_t)j * ld + D + d]), acc);
-        sred[w][d] = acc;
-    }
+    // dq_0[8c+e] = sum over the 32 key groups
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sred[grp][8 * c + e] = dq[e];
     __syncthreads();
     if (tid < 64) {
-        float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+        float v = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) v += sred[g][tid];
         dqkv[(size_t)(img * T) * ldd + head * 64 + tid] = f32_to_op(v * SCALE);
     }
 }
@@ -442,7 +445,6 @@ hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, co
 hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s) {
-    if (T > 320) return hipErrorInvalidValue;
     if (need_dk)
         hipLaunchKernelGGL((attn_bwd_cls_kernel<true>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
                            ld_dqkv, T, H);

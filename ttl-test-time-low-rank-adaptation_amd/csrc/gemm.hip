@@ -43,7 +43,8 @@ struct SchedLoop<NP, NP, NP0, MPER, DPER> {
 // residual / aux buffers (the context pads its arena), so the epilogue is straight-line code: with
 // a per-row branch hipcc re-waits vmcnt(0) in every store block and the stores serialise.
 template <int EPI, int MT, bool GUARD>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg, int M) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg, int M,
+                                              const u32x2 (*auxr)[4] = nullptr) {
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) bias = *(const float4*)(a.bias + n0);
 #pragma unroll
@@ -72,7 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
                 if constexpr (EPI == EPI_GELU_BWD) {
-                    u32x2 t = *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
+                    u32x2 t = auxr ? auxr[mt][r] : *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
                     v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
                     v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
                 }
@@ -184,6 +185,16 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = MFMA16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
     };
+    // MLP-dgrad epilogue multiplies by gelu'(u): fetch u (8 B per lane per row) BEFORE the K loop so its
+    // latency hides under the MFMAs instead of sitting at the end of the tile (40 VGPRs)
+    u32x2 auxr[(EPI == EPI_GELU_BWD && !GUARD) ? MT : 1][4];
+    if constexpr (EPI == EPI_GELU_BWD && !GUARD) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                auxr[mt][r] = *(const u32x2*)(a.aux + (size_t)(row0 + wm * WM + mt * 16 + 4 * lg + r) * a.ldaux + col0 + wn * 64 + 4 * li);
+    }
     if constexpr (STAGES == 2) {
         stage(0, 0);
         // steady state: tile kt is consumed while tile kt+1's DMA is issued BETWEEN the MFMAs (the
@@ -236,7 +247,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     }
     GemmArgs e = a;
     if (EPI == EPI_F32 && a.splits > 1) e.C = (float*)a.C + (size_t)blockIdx.y * M * a.ldc;
-    gemm_epilogue<EPI, MT, GUARD>(e, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
+    if constexpr (EPI == EPI_GELU_BWD && !GUARD)
+        gemm_epilogue<EPI, MT, GUARD>(e, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M, auxr);
+    else
+        gemm_epilogue<EPI, MT, GUARD>(e, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
 }
 
 template <int BM, int WMW, int WNW, int EPI, bool GUARD = true, int STAGES = 2>
