@@ -12,6 +12,8 @@
 // LDS tiles are [rows][64] bf16 (128 B rows) filled by global_load_lds_dwordx4; 16-B chunk c of
 // row r sits at slot c ^ f(r), f(r) = ((r>>1)&1)<<2 | ((r>>2)&3): conflict-free for the
 // ds_read_b128 row reads AND for the transposed 4x16 block reads.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace {
@@ -25,14 +27,16 @@ __device__ __forceinline__ int tile_off(int row, int col) {
 
 // DMA rows [0,TP) of a [T][64] bf16 matrix (row stride ld elements) into a swizzled LDS tile;
 // rows >= T replicate row T-1 (finite data; their results are masked).
-template <int NKT>
+template <int NKT, int NW = 4>
 __device__ __forceinline__ void stage_tile(char* lds, const op_t* g, int ld, int T, int tid, int wave) {
+    constexpr int NTHR = 64 * NW, NPASS = (NKT * 256 + NTHR - 1) / NTHR;   // TP rows x 8 chunks of 16 B
 #pragma unroll
-    for (int i = 0; i < NKT; ++i) {  // 32 rows x 8 chunks = 256 chunks per pass
-        int q = i * 256 + tid, r = q >> 3, p = q & 7;
+    for (int i = 0; i < NPASS; ++i) {
+        int q = i * NTHR + tid, r = q >> 3, p = q & 7;
+        if (NKT * 256 % NTHR != 0 && q >= NKT * 256) break;   // whole waves drop out (256 % 64 == 0)
         int c = p ^ swz(r);
         const op_t* src = g + (size_t)min(r, T - 1) * ld + c * 8;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
 }
 
@@ -155,9 +159,109 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------ forward, one wave per query block
+// NKT waves per workgroup, wave w owns query rows 32w..32w+31: all query blocks of a (view, head)
+// run at once, and the scores are processed in chunks of CH key tiles with an online softmax so a
+// wave needs ~125 VGPRs (the whole-row version needs 256): two 7-wave workgroups per CU = 3.5 waves
+// per SIMD hide the LDS / exp latency that the 4-wave version (2 per SIMD) exposed.
+template <int NKT, int CH>
+__global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
+                                                             int ldo, float* __restrict__ lse, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32, NTHR = 64 * NKT;
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    // this wave's Q fragments first: their latency hides under the K/V staging
+    const int q = wave * 32 + (lane & 31);
+    const int qrow = min(q, T - 1);
+    opx8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = global_frag(qg, ld, qrow, ks, lane);
+    // stage K and V: TP*8 chunks of 16 B each, NTHR chunks per pass -> 4 passes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c16 = i * NTHR + tid, r = c16 >> 3, p = c16 & 7;
+        int c = p ^ swz(r);
+        size_t go = (size_t)min(r, T - 1) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(qg + D + go), LDS_PTR(sK + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(qg + 2 * D + go), LDS_PTR(sV + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+    }
+    __syncthreads();
+    if (wave * 32 >= T) return;   // (never for NKT = ceil(T/32); kept for safety — after the only barrier)
+
+    constexpr float C2 = SCALE * 1.4426950408889634f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2] = {};
+#pragma unroll
+    for (int c0 = 0; c0 < NKT; c0 += CH) {
+        f32x16 st[CH];
+        float mx = m_run;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int kt = c0 + j;
+            if (kt < NKT) {
+                f32x16 a = {};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
+                if (32 * kt + 32 > T) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * kt + acc_row(r, lane) >= T) a[r] = -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, a[r]);
+                st[j] = a;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * C2;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * C2 - mc);   // 0 on the first chunk (m_run = -inf)
+        m_run = mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (c0 + j < NKT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[j][r], C2, -mc));
+                    st[j][r] = p;
+                    sum += p;
+                }
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        if (c0 > 0) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (c0 + j < NKT) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    opx8 pf = acc_frag(st[j], s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = MFMA32(tr_frag(sV, 32 * (c0 + j) + 16 * s, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    if (q < T) {
+        store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / l_run, lane);
+        if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = m_run * SCALE + __logf(l_run);
+    }
+}
+
 // ------------------------------------------------------------------------------ backward: dQ
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
+template <int NKT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
                                                           const op_t* __restrict__ out, const op_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse,
                                                           op_t* __restrict__ dqkv, int ldd, int T, int H) {
@@ -172,12 +276,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op_t* __restrict
     const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
     const op_t* og = out + (size_t)img * T * ldo + head * 64;
     const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
-    stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
-    stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
+    stage_tile<NKT, NW>(sK, qg + D, ld, T, tid, wave);
+    stage_tile<NKT, NW>(sV, qg + 2 * D, ld, T, tid, wave);
     __syncthreads();
 
     const int nqb = (T + 31) >> 5;
-    for (int qb = wave; qb < nqb; qb += 4) {
+    for (int qb = wave; qb < nqb; qb += NW) {
         const int q = qb * 32 + (lane & 31);
         const int qrow = min(q, T - 1);
         opx8 qf[4], dof[4];
@@ -193,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op_t* __restrict
         delta += __shfl_xor(delta, 32, 64);
         const float l = lse[((size_t)img * H + head) * T + qrow];
         f32x16 dq[2] = {};
-#pragma unroll
+#pragma unroll 1
         for (int kt = 0; kt < NKT; ++kt) {
             f32x16 s = {}, dp = {};
 #pragma unroll
@@ -220,8 +324,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op_t* __restrict
 }
 
 // ------------------------------------------------------------------------------ backward: dK, dV
-template <int NKT, bool NEED_DK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const op_t* __restrict__ qkv, int ld,
+template <int NKT, bool NEED_DK, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __restrict__ qkv, int ld,
                                                            const op_t* __restrict__ out,
                                                            const op_t* __restrict__ dout, int ldo,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv,
@@ -239,9 +343,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const op_t* __restric
     const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
     const op_t* og = out + (size_t)img * T * ldo + head * 64;
     const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
-    stage_tile<NKT>(sQ, qg, ld, T, tid, wave);
-    stage_tile<NKT>(sDO, dog, ldo, T, tid, wave);
-    for (int t = tid; t < TP; t += 256) {
+    stage_tile<NKT, NW>(sQ, qg, ld, T, tid, wave);
+    stage_tile<NKT, NW>(sDO, dog, ldo, T, tid, wave);
+    for (int t = tid; t < TP; t += 64 * NW) {
         int row = min(t, T - 1);
         float d = 0.f;
 #pragma unroll
@@ -257,7 +361,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const op_t* __restric
     __syncthreads();
 
     const int nkb = (T + 31) >> 5;
-    for (int kb = wave; kb < nkb; kb += 4) {
+    for (int kb = wave; kb < nkb; kb += NW) {
         const int key = kb * 32 + (lane & 31);
         const int krow = min(key, T - 1);
         opx8 kf[4], vf[4];
@@ -384,6 +488,15 @@ hipError_t set_smem(K kernel, int bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+template <int NKT, int CH>
+hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+    constexpr int SMEM = 2 * NKT * 32 * 128;
+    static bool done = false;
+    if (!done) { hipError_t e = set_smem(attn_fwd_w_kernel<NKT, CH>, SMEM); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((attn_fwd_w_kernel<NKT, CH>), dim3(n * H), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H);
+    return hipGetLastError();
+}
+
 template <int NKT>
 hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
@@ -396,23 +509,25 @@ hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n,
 template <int NKT>
 hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
                  op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s) {
+    // one wave per 32-row block (NKT waves) for the ViT geometries, 4 waves otherwise
+    constexpr int NW = 4;   // (one wave per block, NW = NKT, measured slower here: the dQ pass needs 256 VGPRs)
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
     constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
     static bool done = false;
     if (!done) {
-        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT>, SMEM_A);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true>, SMEM_B);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false>, SMEM_B);
+        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT, NW>, SMEM_A);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true, NW>, SMEM_B);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false, NW>, SMEM_B);
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT>), dim3(n * H), dim3(256), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, NW>), dim3(n * H), dim3(64 * NW), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
                        ldd, T, H);
     if (need_dk)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true>), dim3(n * H), dim3(256), SMEM_B, s, qkv, ld, out, dout, ldo,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
                            lse, dqkv, ldd, T, H);
     else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false>), dim3(n * H), dim3(256), SMEM_B, s, qkv, ld, out, dout, ldo,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
                            lse, dqkv, ldd, T, H);
     return hipGetLastError();
 }
@@ -425,6 +540,14 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
     if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    static int variant = -1;
+    if (variant < 0) { const char* v = getenv("TTL_ATTN_VARIANT"); variant = v ? atoi(v) : 1; }
+    if (variant >= 1) {
+        if (nkt == 7 && variant == 2) return fwd_w<7, 1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+        if (nkt == 7 && variant == 3) return fwd_w<7, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+        if (nkt == 7) return fwd_w<7, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+        if (nkt == 9) return fwd_w<9, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    }
     if (nkt <= 7) return fwd_t<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     if (nkt <= 9) return fwd_t<9>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     return hipErrorInvalidValue;
