@@ -39,32 +39,46 @@ __global__ void refresh_kernel(const float* __restrict__ Aq, const float* __rest
 
 // One wave: 16 rows of X times all 2r columns.  MFMA A operand = Wcat rows (output row = column
 // c of the result), B operand = X rows (output column = token) -> each lane ends with 4
-// consecutive result columns of one token: one 8-byte store.
-template <int NCG>
+// consecutive result columns of one token: one 8-byte store.  The kernel is pure latency (a
+// few hundred waves, each a serial K loop), so ALL of a wave's X fragments are requested up
+// front (KS x 16 B per lane in flight) and Wcat is staged once per workgroup in LDS.
+template <int NCG, int KS>   // KS = D / 32 k-steps
 __global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X, int ldx, int xoff_q, int xoff_v,
                                                      const op_t* __restrict__ W, int D, float scale,
                                                      op_t* __restrict__ out, int ldo, int M) {
-    const int lane = threadIdx.x & 63;
-    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-    if (m0 >= M) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // Wcat [16*NCG][D] operand type, rows padded by 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rowb = D * 2 + 16;
+    for (int q = tid; q < 16 * NCG * (D / 8); q += 256) {
+        int r = q / (D / 8), c = q - r * (D / 8);
+        *(u32x4*)(smem + r * rowb + c * 16) = *(const u32x4*)(W + (size_t)r * D + c * 8);
+    }
+    const int m0 = (blockIdx.x * 4 + (tid >> 6)) * 16;
     const int li = lane & 15, lg = lane >> 4;
     const int row = min(m0 + li, M - 1);
+    const bool same = (xoff_q == xoff_v);
     const op_t* xq = X + (size_t)row * ldx + xoff_q + 8 * lg;
     const op_t* xv = X + (size_t)row * ldx + xoff_v + 8 * lg;
-    const bool same = (xoff_q == xoff_v);
+    opx8 fq[KS], fv[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) fq[k] = *(const opx8*)(xq + 32 * k);
+    if (!same) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) fv[k] = *(const opx8*)(xv + 32 * k);
+    }
+    __syncthreads();
     f32x4 acc[NCG];
 #pragma unroll
     for (int c = 0; c < NCG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < D; k += 32) {
-        opx8 fq = *(const opx8*)(xq + k);
-        opx8 fv = same ? fq : *(const opx8*)(xv + k);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
 #pragma unroll
         for (int c = 0; c < NCG; ++c) {
-            opx8 w = *(const opx8*)(W + (size_t)(c * 16 + li) * D + k + 8 * lg);
-            acc[c] = MFMA16(w, (c < NCG / 2) ? fq : fv, acc[c], 0, 0, 0);
+            opx8 w = *(const opx8*)(smem + (c * 16 + li) * rowb + (32 * k + 8 * lg) * 2);
+            acc[c] = MFMA16(w, (c < NCG / 2 || same) ? fq[k] : fv[k], acc[c], 0, 0, 0);
         }
     }
-    if (m0 + li < M) {
+    if (m0 < M && m0 + li < M) {
 #pragma unroll
         for (int c = 0; c < NCG; ++c)
             *(u32x2*)(out + (size_t)(m0 + li) * ldo + c * 16 + 4 * lg) =
@@ -173,14 +187,30 @@ hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av
     return hipGetLastError();
 }
 
+template <int NCG, int KS>
+static hipError_t skinny_launch(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, float scale, op_t* out,
+                                int ldo, int M, hipStream_t s) {
+    const int smem = 16 * NCG * (D * 2 + 16);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_kernel<NCG, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 63) / 64), dim3(256), smem, s, X, ldx, xoff_q, xoff_v, Wcat, D, scale, out,
+                       ldo, M);
+    return hipGetLastError();
+}
+
 hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, int r,
                               float scale, op_t* out, int ldo, int M, hipStream_t s) {
-    if (D % 32) return hipErrorInvalidValue;
-    dim3 grid((M + 63) / 64), block(256);
-    if (r == 16) hipLaunchKernelGGL((skinny_kernel<2>), grid, block, 0, s, X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M);
-    else if (r == 32) hipLaunchKernelGGL((skinny_kernel<4>), grid, block, 0, s, X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
+    const int ncg = 2 * r / 16, ks = D / 32;
+#define SK(N_, K_) if (ncg == N_ && ks == K_ && D % 32 == 0) return skinny_launch<N_, K_>(X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M, s)
+    SK(2, 24); SK(4, 24);      // ViT-B/16, r = 16 / 32
+    SK(2, 32); SK(4, 32);      // ViT-L/14
+    SK(2, 4);  SK(4, 4);       // reduced test geometry (D = 128)
+#undef SK
+    return hipErrorInvalidValue;
 }
 
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
