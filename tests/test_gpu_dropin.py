@@ -141,3 +141,39 @@ def test_reference_formulation_through_autograd():
     with torch.no_grad():
         out = model(x[:1])
     assert max_rel(out.cpu().numpy(), g["logits1"]) < 3e-2
+
+
+def test_eval_loop_matches_per_image_surface():
+    """ttl_amd.eval.test_time_adapt_eval (fused episodes, 2 in flight) == the reference-shaped per-image
+    sequence (LoRA_reset, load_state_dict, test_time_tuning, model(image)) on the same items."""
+    from ttl_amd.eval import test_time_adapt_eval, SyntheticViews
+    from ttl_amd.ttl import test_time_tuning
+    from ttl_amd.driver import topk_hits
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    args = ref_args()
+    data = SyntheticViews(cfg, 6, 8, 10, seed=3)
+    hits = torch.zeros(2, dtype=torch.int64)
+    for views, label in data:
+        with torch.no_grad():
+            model.LoRA_reset()
+        opt.load_state_dict(opt_state)
+        test_time_tuning(model, views.cuda(), opt, None, args)
+        with torch.no_grad():
+            out = model(views[:1].cuda())
+        h1, h5 = topk_hits(out.cpu(), torch.tensor([label]))
+        hits += torch.stack([h1, h5])
+    with torch.no_grad():
+        model.LoRA_reset()
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=2)
+    assert abs(top1 - 100.0 * hits[0].item() / 6) < 1e-9 and abs(top5 - 100.0 * hits[1].item() / 6) < 1e-9
+    # sharded over two "ranks" (no process group: world=1 per call, disjoint index sets) the hit counts add up
+    from ttl_amd import eval as E
+    parts = []
+    for r in range(2):
+        class Shard:
+            def __iter__(self_inner):
+                for i, item in enumerate(data):
+                    if i % 2 == r:
+                        yield item
+        parts.append(E.test_time_adapt_eval(Shard(), model, None, opt, opt_state, None, args, n_streams=1))
+    assert abs((parts[0][0] + parts[1][0]) / 2 - top1) < 1e-9

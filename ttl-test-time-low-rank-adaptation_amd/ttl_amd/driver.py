@@ -105,6 +105,9 @@ class EpisodePipeline:
         sl = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         sl["stream"].wait_stream(torch.cuda.current_stream())
+        views.record_stream(sl["stream"])          # the caching allocator must not recycle it under the slot's stream
+        if target is not None:
+            target.record_stream(sl["stream"])
         with torch.cuda.stream(sl["stream"]):
             out = sl["eng"].episode(views, sl["snap"], sl["m"], sl["v"], **episode_kw)
             if target is not None:

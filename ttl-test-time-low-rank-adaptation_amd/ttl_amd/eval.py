@@ -1,0 +1,139 @@
+"""Evaluation loop over a dataset — this build's counterpart of ``test_time_adapt_eval``
+(ttl.py:300-363), with the per-image body fused into one enqueue and images sharded over ranks.
+
+    export PYTHONPATH=ttl-test-time-low-rank-adaptation_amd
+    python -m ttl_amd.eval --arch ViT-B/16 --images 256 --views 64 --classes 200
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ttl_amd.eval ...
+
+Semantics kept from the reference loop: model.eval(); per image LoRA reset + empty Adam state
+(ttl.py:338-344), adaptation on all views (ttl.py:347), prediction on view 0 with the adapted
+weights (ttl.py:350-352), top-1 / top-5 as hit percentages (utils/tools.py:88-102).  What differs:
+text features are cached per dataset (Q12), ``n_streams`` images are in flight per GPU, and
+rank r takes the items i with i % world == r; ONE all-reduce(SUM) of [hits1, hits5, count]
+ends the dataset (RCCL over xGMI on GPUs).
+"""
+import argparse
+import json
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import synth
+from .driver import EpisodePipeline, dist_env
+
+
+def episode_kwargs_from_args(args):
+    """Reference CLI semantics -> fused-episode arguments (incl. tta_steps**2 on the DeYO branch, Q6)."""
+    deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
+    return dict(n_updates=(args.tta_steps ** 2 if deyo else args.tta_steps), objective="deyo" if deyo else "tpt",
+                mode=1 if getattr(args, "filter_ent", 0) else 0, rho=args.selection_p, margin=args.deyo_margin_e0,
+                reweight=float(getattr(args, "reweight_ent", 1)), lr=args.lr)
+
+
+def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state, scaler, args, n_streams=2,
+                         rank=0, world=1):
+    """Same call shape as ttl.py:300.  ``val_loader`` yields (images, target) with images either a
+    list of [1,3,S,S] tensors (view 0 first, like AugMixAugmenter) or one [N,3,S,S] tensor.
+    ``optimizer`` supplies the AdamW hyper-parameters; ``model_state``/``optim_state``/``scaler`` are
+    accepted for signature compatibility (the fused episode resets LoRA and Adam state itself).
+    Returns [top1, top5] in percent, identical on every rank."""
+    from .deyo import _adam_hparams
+    model.eval()
+    eng = model._ensure_engine()
+    _, lr, betas, eps, wd = _adam_hparams(optimizer, model)
+    kw = episode_kwargs_from_args(args)
+    kw.update(lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    names = [f"p{i}" for i in range(len(model.trainable_lora_parameters()))]
+    init = {n: t for n, t in zip(names, _split(model.snapshot_flat(), model.trainable_lora_parameters()))}
+    pipe = EpisodePipeline(model.cfg, model._vision_state, names, init, model.text_features,
+                           float(model.logit_scale.exp()), eng.device, n_streams=n_streams, max_views=eng.max_views,
+                           precision=model.precision)
+    dev = eng.device
+    for i, (images, target) in enumerate(val_loader):
+        if i % world != rank:
+            continue
+        if isinstance(images, (list, tuple)):
+            images = torch.cat([im.to(dev, non_blocking=True) for im in images], dim=0)     # ttl.py:324-336
+        else:
+            images = images.to(dev, non_blocking=True)
+            if images.dim() == 5:
+                images = images.squeeze(0)
+        tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev)
+        pipe.submit(images, target=tgt, **kw)
+    acc = pipe.totals()
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    pipe.close()
+    h1, h5, cnt = (int(v) for v in acc.tolist())
+    return [100.0 * h1 / max(cnt, 1), 100.0 * h5 / max(cnt, 1)]
+
+
+test_time_adapt_eval.__test__ = False  # not a pytest test
+
+
+def _split(flat, like):
+    out, off = [], 0
+    for p in like:
+        out.append(flat[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    return out
+
+
+class SyntheticViews:
+    """Deterministic stand-in for the AugMix view generator: item i -> ([N,3,S,S] views, label)."""
+
+    def __init__(self, cfg, n_items, n_views, n_classes, seed=0):
+        self.cfg, self.n, self.v, self.k, self.seed = cfg, n_items, n_views, n_classes, seed
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield torch.from_numpy(synth.views(self.cfg, self.v, self.seed * 100003 + i)), i % self.k
+
+
+def main():
+    ap = argparse.ArgumentParser(description="TTL evaluation on synthetic views (no datasets on the GPU box)")
+    ap.add_argument("--arch", default="ViT-B/16")
+    ap.add_argument("--images", type=int, default=64)
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=200)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--lr", type=float, default=5e-3)
+    ap.add_argument("--tta_steps", type=int, default=1)
+    ap.add_argument("--selection_p", type=float, default=0.1)
+    ap.add_argument("--filter_ent", type=int, default=0)
+    ap.add_argument("--deyo_selection", default=True)
+    ap.add_argument("--deyo_margin_e0", type=float, default=0.4)
+    ap.add_argument("--reweight_ent", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--precision", default="bf16")
+    a = ap.parse_args()
+    a.lora_encoder = "image"
+    rank, local, world = dist_env()
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from .config import get_config
+    from .custom_clip import ClipTestTimeTuning
+    cfg = get_config(a.arch)
+    model = ClipTestTimeTuning(local, [f"class {i}" for i in range(a.classes)], None, arch=a.arch,
+                               layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier", lora_encoder="image",
+                               rank=a.rank, max_views=a.views, max_classes=a.classes, precision=a.precision)
+    opt = torch.optim.AdamW([{"params": [p]} for p in model.trainable_lora_parameters()], lr=a.lr)
+    data = SyntheticViews(model.cfg, a.images, a.views, a.classes)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world)
+    dt = time.time() - t0
+    if rank == 0:
+        print(json.dumps({"top1": top1, "top5": top5, "images": a.images, "world": world,
+                          "images_per_sec_incl_host_view_generation": round(a.images / dt, 2)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
