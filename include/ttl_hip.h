@@ -100,11 +100,14 @@ int ttl_vit_forward(ttl_ctx* ctx, const float* x, int n_views, int save_for_back
  *   H_out [N]; idx_out [N] int64 (first *n_out valid; index order for LE_THRESH, entropy order
  *   for TOPK — the order torch returns); n_out [1] int32; loss_out [1]; dlogits_out [N,K]
  *   (zero rows for unselected views; all zero and loss 0 when n == 0, deyo.py:110-113).
+ *   keep (device uint8 [N] or NULL): second-stage filter — a selected view with keep[i] == 0 is dropped
+ *   before the loss (the PLPD filter of deyo.py:144-151); idx_out still lists the first-stage set,
+ *   *n_out is the surviving count.
  *   Any output pointer except dlogits_out/n_out may be NULL. */
 int ttl_entropy_select_loss(const float* logits, int n_views, int n_classes, int mode, double rho,
-                            float thresh, float margin, float reweight, float* H_out,
-                            int64_t* idx_out, int* n_out, float* loss_out, float* dlogits_out,
-                            void* stream);
+                            float thresh, float margin, float reweight, const unsigned char* keep,
+                            float* H_out, int64_t* idx_out, int* n_out, float* loss_out,
+                            float* dlogits_out, void* stream);
 
 /* TPT objective: select_confident_samples + avg_entropy and its gradient, ttl.py:50-61,87-108.
  *   reuse_idx != 0: use idx_io[0..*n_io) chosen by an earlier step (ttl.py:97-98). */

@@ -113,8 +113,21 @@ def select_views(H, mode, n_views, rho=0.1, thresh=LN1000):
     raise ValueError(mode)
 
 
-def deyo_loss_and_grad(z, mode="le_thresh", rho=0.1, margin=0.4, reweight=1.0):
+def plpd_keep(z, z_prime, idx, threshold):
+    """deyo.py:137-151: PLPD_i = p_i[c_i] - p'_i[c_i] with c_i = argmax p_i over the first-stage
+    selection ``idx``; returns (plpd [len(idx)], bool keep mask over ALL views)."""
+    p = np.exp(log_softmax(z[idx].astype(np.float32)))
+    pp = np.exp(log_softmax(z_prime.astype(np.float32)))
+    c = p.argmax(1)
+    plpd = p[np.arange(len(idx)), c] - pp[np.arange(len(idx)), c]
+    keep = np.zeros(z.shape[0], bool)
+    keep[idx] = plpd > np.float32(threshold)
+    return plpd.astype(np.float32), keep
+
+
+def deyo_loss_and_grad(z, mode="le_thresh", rho=0.1, margin=0.4, reweight=1.0, keep=None):
     """a4+a5+a6 (deyo.py:102-113,159-181) with the analytic gradient of SURVEY appendix A.
+    ``keep``: optional bool mask [N], the second-stage (PLPD) filter of deyo.py:144-151.
 
     Returns dict(H, idx, coeff, loss, dz).  n == 0 -> loss None, dz zeros (deyo.py:110-113).
     """
@@ -124,6 +137,8 @@ def deyo_loss_and_grad(z, mode="le_thresh", rho=0.1, margin=0.4, reweight=1.0):
     p = np.exp(lp)
     H = -(p * lp).sum(-1).astype(np.float32)
     idx = select_views(H, mode, N, rho)
+    if keep is not None:
+        idx = idx[np.asarray(keep, bool)[idx]]
     n = idx.size
     dz = np.zeros_like(z)
     if n == 0:
@@ -373,7 +388,7 @@ def trainable_names(cfg):
 
 def episode(cfg, W, lora0, x, tfeat, *, prec="fp32", objective="deyo", mode="le_thresh",
             rho=0.1, margin=0.4, reweight=1.0, n_updates=1, lr=5e-3, betas=(0.9, 0.999),
-            eps=1e-8, wd=1e-2, trace=None):
+            eps=1e-8, wd=1e-2, trace=None, keep=None):
     """One test image: reset -> n_updates x [N-view forward, loss, LoRA backward, AdamW]
     -> adapted inference on view 0 (ttl.py:338-352).  ``n_updates`` is the *effective*
     number of optimizer steps (tta_steps**2 on the reference's DeYO branch, Q6).
@@ -395,7 +410,7 @@ def episode(cfg, W, lora0, x, tfeat, *, prec="fp32", objective="deyo", mode="le_
         if logits0 is None:
             logits0 = z
         if objective == "deyo":
-            L = deyo_loss_and_grad(z, mode, rho, margin, reweight)
+            L = deyo_loss_and_grad(z, mode, rho, margin, reweight, keep)   # keep: PLPD mask supplied by the caller
         else:
             L = tpt_loss_and_grad(z, tpt_idx, rho)
             tpt_idx = L["idx"]

@@ -50,8 +50,16 @@ def install_import_stubs():
         BILINEAR = 2
     names = ["Compose", "Resize", "CenterCrop", "ToTensor", "Normalize", "RandomResizedCrop",
              "RandomHorizontalFlip", "Lambda", "ToPILImage"]
+    class _Resize:   # torchvision.transforms.Resize on a tensor (>= 0.17): bilinear + antialias
+        def __init__(self, size, *a, **k):
+            self.size = tuple(size) if isinstance(size, (tuple, list)) else (size, size)
+
+        def __call__(self, x):
+            import torch.nn.functional as Fn
+            return Fn.interpolate(x, size=self.size, mode="bilinear", align_corners=False, antialias=True)
     tfm = _mod("torchvision.transforms", InterpolationMode=_Interp,
                **{n: type(n, (_Anything,), {}) for n in names})
+    tfm.Resize = _Resize
     models = _mod("torchvision.models")
     dsets = _mod("torchvision.datasets", ImageFolder=type("ImageFolder", (_Anything,), {}),
                  VisionDataset=type("VisionDataset", (_Anything,), {}))

@@ -37,6 +37,7 @@ CASES = {
     "tiny_r32": ("tiny", 8, 10, {"rank": 32}),
     "tiny_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
     "tiny197_deyo": ("tiny197", 8, 10, {}),
+    "tiny_plpd": ("tiny", 64, 10, {"filter_plpd": 1, "plpd_threshold": 0.17}),
     "b16_n8_k10": ("ViT-B/16", 8, 10, {}),
     "b16_n64_k200_ent0": ("ViT-B/16", 64, 200, {}),
     "b16_n64_k200_ent1": ("ViT-B/16", 64, 200, {"filter_ent": 1}),
@@ -130,6 +131,7 @@ def run_case(case):
     with torch.no_grad():
         model.LoRA_reset()
     opt.load_state_dict(opt_state)
+    torch.manual_seed(4321)        # the PLPD patch permutation draws torch.rand from the CPU generator
     ttl.test_time_tuning(model, x, opt, scaler, args)
     grads = {k: (p.grad.detach().clone().numpy() if p.grad is not None else None)
              for k, p in lora_named(model).items()}
@@ -156,7 +158,21 @@ def run_case(case):
         coeff = torch.zeros(0)
         loss = ttl.avg_entropy(sel.float())
     n_updates = args.tta_steps ** 2 if args.deyo_selection else args.tta_steps
-    assert len(rec["logits"]) == n_updates + 1, (len(rec["logits"]), n_updates)
+    n_fwd = n_updates * (2 if args.filter_plpd else 1) + 1
+    assert len(rec["logits"]) == n_fwd, (len(rec["logits"]), n_fwd)
+    if args.filter_plpd:    # second stage of the first update, through the reference's formulae (deyo.py:137-151)
+        zp = rec["logits"][1]
+        prob, prob_p = z0[idx].softmax(1), zp.softmax(1)
+        cls1 = prob.argmax(dim=1)
+        plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_p, 1, cls1.reshape(-1, 1))).reshape(-1)
+        ids2 = torch.where(plpd > args.plpd_threshold)[0]
+        e2 = Hs[idx][ids2]
+        coeff = args.reweight_ent * (1 / torch.exp(e2.clone().detach() - args.deyo_margin_e0))
+        loss = e2.mul(coeff).mean(0)
+        extra = dict(plpd=plpd.numpy(), idx2=idx[ids2].numpy().astype(np.int64), logits_prime=zp.numpy(),
+                     plpd_threshold=args.plpd_threshold, patch_len=args.patch_len, rng_seed=4321)
+    else:
+        extra = {}
     trained = [k for k in lora0 if any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1))]
     out = dict(
         arch=cfg.name, rank=cfg.rank, n_views=N, n_classes=K, weight_seed=0, view_seed=7,
@@ -167,8 +183,9 @@ def run_case(case):
         rho=args.selection_p, margin=args.deyo_margin_e0, n_updates=n_updates, lr=args.lr,
         text_features=tfeat, logits0=z0.numpy(), H=Hs.numpy(), idx=idx.numpy().astype(np.int64),
         coeff=coeff.numpy(), loss=np.float32(loss.item()),
-        logits_last=rec["logits"][n_updates - 1].numpy(),
+        logits_last=rec["logits"][n_fwd - 2 - (1 if args.filter_plpd else 0)].numpy(),
         logits1=out1.numpy(), top5=torch.topk(out1, min(5, K), dim=1).indices.numpy())
+    out.update(extra)
     for k in (lora0 if cfg.width <= 128 else trained):
         out["lora0/" + k] = lora0[k]
     for k in trained:

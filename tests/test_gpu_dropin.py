@@ -177,3 +177,29 @@ def test_eval_loop_matches_per_image_surface():
                         yield item
         parts.append(E.test_time_adapt_eval(Shard(), model, None, opt, opt_state, None, args, n_streams=1))
     assert abs((parts[0][0] + parts[1][0]) / 2 - top1) < 1e-9
+
+
+def test_plpd_filter_matches_reference():
+    """--filter_plpd 1 (deyo.py:115-151) through this build's test_time_tuning: same destroyed views (the patch
+    permutation comes from torch's CPU generator, seeded like the fixture), same surviving set, same counts."""
+    import torch.nn.functional as F  # noqa: F401
+    from ttl_amd.ttl import test_time_tuning
+    from ttl_amd import deyo as D
+    g, cfg, model, opt, opt_state, x = build("tiny_plpd")
+    model.precision = "fp16"          # PLPD thresholds a probability difference: use the tighter build
+    args = ref_args(filter_plpd=1, plpd_threshold=float(g["plpd_threshold"]), aug_type="patch", patch_len=int(g["patch_len"]))
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    torch.manual_seed(int(g["rng_seed"]))
+    d = D.DeYO(model, args, opt, None, steps=1, deyo_margin=args.deyo_margin, margin_e0=args.deyo_margin_e0)
+    outputs, backward, final_backward = d(x)
+    assert backward == len(g["idx"]) and final_backward == len(g["idx2"])
+    assert max_rel(outputs.cpu().numpy(), g["logits0"]) < 2e-3
+    lora1 = named_lora(model, cfg)
+    frac_bad = np.mean([float((np.abs(lora1[k] - g["lora1/" + k]) > 1e-3).mean()) for k in lora1])
+    assert frac_bad < 0.05, frac_bad
+    with torch.no_grad():
+        out = model(x[:1])
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 5e-3
+    assert int(out.argmax()) == int(g["top5"][0, 0])

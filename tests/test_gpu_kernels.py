@@ -153,7 +153,7 @@ def test_entropy_select_loss_vs_reference(lib, unit, s, mode):
     loss = torch.zeros(1, device="cuda")
     dz = torch.empty_like(z)
     m = 0 if mode == "le_thresh" else 1
-    chk(lib, lib.ttl_entropy_select_loss(P(z), N, K, m, 0.1, math.log(1000.0), 0.4, 1.0, P(H), P(idx), P(n), P(loss), P(dz), S()))
+    chk(lib, lib.ttl_entropy_select_loss(P(z), N, K, m, 0.1, math.log(1000.0), 0.4, 1.0, None, P(H), P(idx), P(n), P(loss), P(dz), S()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.cpu().numpy(), unit[f"{s}/H"], rtol=2e-5, atol=2e-6)
     nn = int(n.item())

@@ -104,3 +104,20 @@ def test_bf16_mode_is_close_to_fp32():
     a = z32.logits(z32.forward(x), tf)
     b = z16.logits(z16.forward(x), tf)
     assert max_rel(b, a) < 3e-2
+
+
+def test_plpd_filter_against_reference():
+    """deyo.py:115-151 (filter_plpd=1): the second-stage mask from the reference's own destroyed-view logits,
+    then loss / grads / post-step weights of the surviving views."""
+    g, cfg, W, x, lora0, tf = load_case("tiny_plpd")
+    plpd, keep = O.plpd_keep(g["logits0"], g["logits_prime"], g["idx"], float(g["plpd_threshold"]))
+    np.testing.assert_allclose(plpd, g["plpd"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(np.nonzero(keep)[0], np.sort(g["idx2"]))
+    trace = []
+    out = O.episode(cfg, W, lora0, x, tf, trace=trace, keep=keep, **episode_kwargs(g))
+    assert np.array_equal(trace[0]["idx"], np.sort(g["idx2"]))
+    assert abs(trace[0]["loss"] - g["loss"]) <= 2e-5 * abs(g["loss"])
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert max_rel(trace[-1]["grads"][k[5:]], g[k]) < 1e-4, k
+    assert max_rel(out["logits1"], g["logits1"]) < 1e-4

@@ -539,7 +539,8 @@ int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_o
 }
 
 int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double rho, float thresh, float margin, float reweight,
-                            float* H_out, int64_t* idx_out, int* n_out, float* loss_out, float* dlogits_out, void* stream) {
+                            const unsigned char* keep, float* H_out, int64_t* idx_out, int* n_out, float* loss_out,
+                            float* dlogits_out, void* stream) {
     if (!logits || !dlogits_out || !n_out) return fail(TTL_EINVAL, "null argument");
     if (N < 1 || K < 1) return fail(TTL_EINVAL, "bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -547,7 +548,7 @@ int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double 
     size_t cnt = 4 * (size_t)N + 3 * (size_t)K + 16;
     HIP_TRY(hipMallocAsync((void**)&scratch, cnt * sizeof(float), s));
     hipError_t e = launch_entropy_loss(logits, N, K, 0, mode, rho, thresh, margin, reweight, 0, H_out, (long long*)idx_out, n_out,
-                                       loss_out, dlogits_out, scratch, s);
+                                       loss_out, dlogits_out, scratch, s, keep);
     (void)hipFreeAsync(scratch, s);
     HIP_TRY(e);
     return 0;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ H
                                                      int ktop, float thresh, float margin, float reweight,
                                                      int reuse_idx, long long* __restrict__ idx, int* __restrict__ n_io,
                                                      float* __restrict__ loss, float* __restrict__ coef /*[N]*/,
-                                                     int* __restrict__ nsel_dev) {
+                                                     int* __restrict__ nsel_dev, const unsigned char* __restrict__ keep) {
     __shared__ float red[4];
     __shared__ int sn;
     __shared__ int wcnt[4];
@@ -199,6 +199,17 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ H
             __syncthreads();
         }
         n = sn;
+    }
+    if (keep) {
+        // second-stage filter (PLPD, deyo.py:144-151): drop selected views whose keep flag is 0; idx keeps
+        // the first-stage order, the loss / gradient / step use the surviving set
+        __syncthreads();
+        float cnt = 0.f;
+        for (int i = tid; i < N; i += 256) {
+            if (coef[i] != 0.f && !keep[i]) coef[i] = 0.f;
+            cnt += coef[i];
+        }
+        n = (int)(block_sum(cnt, red) + 0.5f);
     }
     if (tid == 0) { if (n_io) *n_io = n; *nsel_dev = n; }
     if (objective == 0) {
@@ -334,7 +345,7 @@ hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, o
 //                          | then avg[K] | gk[2K]
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
                                float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io, int* n_io,
-                               float* loss_out, float* dlogits, float* scratch, hipStream_t s) {
+                               float* loss_out, float* dlogits, float* scratch, hipStream_t s, const unsigned char* keep) {
     float* lse = scratch;
     float* coef = scratch + N;
     int* nsel = (int*)(scratch + 2 * N);
@@ -344,7 +355,7 @@ hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective,
     hipLaunchKernelGGL(row_stats_kernel, dim3(N), dim3(256), 0, s, logits, K, H, lse);
     const int ktop = (int)((double)N * rho);  // Python: int(batch_entropy.size()[0] * top), ttl.py:52 / deyo.py:105
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, s, H, N, objective, mode, ktop, thresh, margin, reweight,
-                       reuse_idx, idx_io, n_io, loss_out, coef, nsel);
+                       reuse_idx, idx_io, n_io, loss_out, coef, nsel, keep);
     if (objective == 0) {
         hipLaunchKernelGGL(deyo_grad_kernel, dim3(N), dim3(256), 0, s, logits, K, H, lse, coef, dlogits);
     } else {

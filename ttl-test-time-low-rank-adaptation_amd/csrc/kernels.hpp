@@ -94,8 +94,8 @@ hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls,
 
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
                                float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io,
-                               int* n_io, float* loss_out, float* dlogits, float* scratch /*>= 4*N + K floats*/,
-                               hipStream_t s);
+                               int* n_io, float* loss_out, float* dlogits, float* scratch /*>= 4*N + 3*K + 16 floats*/,
+                               hipStream_t s, const unsigned char* keep = nullptr);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                         float eps, float wd, int step, const int* n_selected, hipStream_t s);
 hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ttl_set_text_features": (_I, [_P, _P, _I, _F, _P]),
     "ttl_bind_lora": (_I, [_P, _P, _P, _Z]),
     "ttl_vit_forward": (_I, [_P, _P, _I, _I, _P, _P, _P]),
-    "ttl_entropy_select_loss": (_I, [_P, _I, _I, _I, _D, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "ttl_entropy_select_loss": (_I, [_P, _I, _I, _I, _D, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "ttl_tpt_select_loss": (_I, [_P, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P]),
     "ttl_vit_backward_lora": (_I, [_P, _P, _I, _P]),
     "ttl_adamw_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),

@@ -327,6 +327,23 @@ class ClipTestTimeTuning(nn.Module):
             self._text_dirty = False
         return self.engine
 
+    def _aux_engine(self):
+        """Second context for forwards that must not disturb the activations saved for a pending backward
+        (the PLPD forward of deyo.py:135 sits between model(x) and loss.backward()).  Shares the LoRA
+        parameter buffer, so it always sees the current adapter weights."""
+        self._ensure_engine()
+        aux = getattr(self, "_aux", None)
+        if aux is None or aux.device != self.engine.device or aux.n_classes != self.engine.n_classes \
+                or getattr(self, "_aux_flat_ptr", None) != self._flat.data_ptr():
+            if aux is not None:
+                aux.close()
+            aux = TTLEngine(self.cfg, self.max_views, self.max_classes, self.engine.device, self.precision)
+            aux.load_weights(self._vision_state)
+            aux.set_text_features(self.text_features, float(self.logit_scale.exp()))
+            aux.bind_lora(self._flat)
+            self._aux, self._aux_flat_ptr = aux, self._flat.data_ptr()
+        return aux
+
     def snapshot_flat(self):
         """Flat copy of LoRA_AB's snapshot for the trained layers (for the fused reset)."""
         if self._snap is None:

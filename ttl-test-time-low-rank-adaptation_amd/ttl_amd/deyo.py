@@ -13,6 +13,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 
@@ -64,8 +65,8 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     """deyo.py:92-196 on the HIP path.  Returns (outputs, backward, final_backward)."""
     if targets is not None:
         raise NotImplementedError("targets / pseudo-label accounting is not part of the TTL hot path")
-    if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
-        raise NotImplementedError("PLPD filtering (deyo.py:115-151) is the next row of SURVEY.md §8f-3")
+    if getattr(args, "reweight_plpd", 0):
+        raise NotImplementedError("reweight_plpd: the term is commented out in the reference (deyo.py:176)")
     eng = model._ensure_engine()
     if not flag:
         return eng.forward(x, save=False)
@@ -74,8 +75,29 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     outputs = eng.forward(x, save=True)                                          # deyo.py:97
     mode = _lib.TTL_SEL_TOPK if getattr(args, "filter_ent", 0) else _lib.TTL_SEL_LE_THRESH
     reweight = float(getattr(args, "reweight_ent", 1))
-    L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
-                                reweight=reweight)                               # deyo.py:102-108,159-181
+    backward = None
+    if getattr(args, "filter_plpd", 0):
+        # PLPD filter (deyo.py:115-151): second forward on destroyed views, keep the views whose
+        # confidence in the predicted class drops by more than plpd_threshold
+        L1 = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
+                                     reweight=reweight)
+        backward = int(L1["n"].item())
+        if backward == 0:
+            return outputs, 0, 0                                                 # deyo.py:110-113
+        ids1 = L1["idx"][:backward]
+        x_prime = plpd_views(x[ids1].detach(), args)
+        outputs_prime = model._aux_engine().forward(x_prime, save=False)         # deyo.py:135
+        prob = outputs[ids1].softmax(1)
+        prob_prime = outputs_prime.softmax(1)
+        cls1 = prob.argmax(dim=1)
+        plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_prime, 1, cls1.reshape(-1, 1))).reshape(-1)
+        keep = torch.zeros(outputs.shape[0], dtype=torch.uint8, device=outputs.device)
+        keep[ids1] = (plpd > args.plpd_threshold).to(torch.uint8)                # deyo.py:146
+        L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
+                                    reweight=reweight, keep=keep)
+    else:
+        L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
+                                    reweight=reweight)                           # deyo.py:102-108,159-181
     eng.backward(L["dlogits"])                                                   # deyo.py:185-186
     for p, gslice in zip(params, _grad_views(eng, params)):
         p.grad = gslice
@@ -87,7 +109,40 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
             optimizer.state[p]["step"] += 1
     if scaler is not None and hasattr(scaler, "update") and getattr(scaler, "is_enabled", lambda: False)():
         pass  # nothing was scaled: there is no inf/nan bookkeeping to feed scaler.update() with
-    return outputs, n, n
+    return outputs, (n if backward is None else backward), n
+
+
+def plpd_views(x_prime, args):
+    """The view-destroying transform of deyo.py:118-134 (host-side torch ops, like the reference).
+    'patch': resize to a multiple of patch_len, permute the patch_len^2 patches of every view with
+    torch.argsort(torch.rand(B, P)) on the CPU generator (the reference's RNG call), resize back;
+    'pixel': one random pixel permutation shared by the batch; 'occ': fill a window with the view mean.
+    torchvision.transforms.Resize on a tensor == bilinear F.interpolate with antialias (torchvision >= 0.17)."""
+    aug = getattr(args, "aug_type", "patch")
+    S = x_prime.shape[-1]
+    if aug == 'occ':
+        mean = x_prime.view(x_prime.shape[0], x_prime.shape[1], -1).mean(dim=2)[:, :, None, None]
+        r0, c0, sz = args.row_start, args.column_start, args.occlusion_size
+        x_prime = x_prime.clone()
+        x_prime[:, :, r0:r0 + sz, c0:c0 + sz] = mean.expand(-1, -1, sz, sz)
+        return x_prime
+    if aug == 'patch':
+        pl = args.patch_len
+        St = (S // pl) * pl
+        xp = F.interpolate(x_prime, size=(St, St), mode="bilinear", align_corners=False, antialias=True)
+        B, Cc = xp.shape[:2]
+        h = St // pl
+        xp = xp.view(B, Cc, pl, h, pl, h).permute(0, 2, 4, 1, 3, 5).reshape(B, pl * pl, Cc, h, h)   # b (ps1 ps2) c h w
+        perm = torch.argsort(torch.rand(B, pl * pl), dim=-1).to(xp.device)
+        xp = xp[torch.arange(B, device=xp.device).unsqueeze(-1), perm]
+        xp = xp.view(B, pl, pl, Cc, h, h).permute(0, 3, 1, 4, 2, 5).reshape(B, Cc, St, St)             # b c (ps1 h) (ps2 w)
+        return F.interpolate(xp, size=(S, S), mode="bilinear", align_corners=False, antialias=True).contiguous()
+    if aug == 'pixel':
+        B, Cc = x_prime.shape[:2]
+        xp = x_prime.reshape(B, Cc, S * S)
+        xp = xp[:, :, torch.randperm(S * S).to(xp.device)]
+        return xp.reshape(B, Cc, S, S).contiguous()
+    raise ValueError(f"unknown aug_type {aug!r}")
 
 
 def _grad_views(eng, params):

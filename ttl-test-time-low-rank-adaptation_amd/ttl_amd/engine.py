@@ -115,8 +115,9 @@ class TTLEngine:
             self._check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
         return self.grads
 
-    def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0):
-        """-> dict(H [N], idx int64 [N] (first n valid), n int32 [1], loss [1], dlogits [N,K]); all device tensors."""
+    def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0, keep=None):
+        """-> dict(H [N], idx int64 [N] (first n valid), n int32 [1], loss [1], dlogits [N,K]); all device tensors.
+        keep: optional uint8/bool [N] second-stage filter (PLPD): selected views with keep == 0 are dropped."""
         import math
         z = logits.to(device=self.device, dtype=torch.float32).contiguous()
         N, K = z.shape
@@ -125,9 +126,10 @@ class TTLEngine:
                    n=torch.zeros(1, dtype=torch.int32, device=dev), loss=torch.zeros(1, device=dev),
                    dlogits=torch.empty_like(z))
         th = math.log(1000.0) if thresh is None else thresh
+        kp = None if keep is None else keep.to(device=dev, dtype=torch.uint8).contiguous()
         with torch.cuda.device(dev):
             self._check(self.lib.ttl_entropy_select_loss(_ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
-                                                        float(reweight), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
+                                                        float(reweight), _ptr(kp), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
                                                         _ptr(out["loss"]), _ptr(out["dlogits"]), _stream()))
         return out
 
