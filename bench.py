@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="independent episodes in flight per GPU (HIP streams)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="MFMA operand dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only for smoke-testing the N>1 logic on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="smoke test: put every rank on cuda:0 (with --backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -95,10 +98,26 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def allreduce(t, op):
+        """all-reduce a small device tensor (through the host when the backend is gloo)"""
+        if world == 1:
+            return t
+        if a.backend == "gloo":
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            return c.to(t.device)
+        dist.all_reduce(t, op=op)
+        return t
 
     from ttl_amd import synth, _lib
     from ttl_amd.config import get_config
@@ -137,9 +156,8 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     hits = pipe.totals()
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(hits, op=dist.ReduceOp.SUM)      # C1: accuracy accumulator (the path's only collective)
+    tmax = allreduce(tmax, dist.ReduceOp.MAX)
+    hits = allreduce(hits, dist.ReduceOp.SUM)            # C1: accuracy accumulator (the path's only collective)
     T = float(tmax.item())
 
     # ---- roofline of the dominant kernel (the MFMA GEMM): HIP events on the launch streams.
