@@ -172,6 +172,20 @@ int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n_views, int t
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                       int ld_dqkv, int n_views, int tokens, int heads, int need_dk, void* stream);
 
+/* GPU-side view generator: replaces the host pipeline data/datautils.py:98-157 with aug_list = [] (Q13)
+ * and ToTensor + Normalize of ttl.py:225-241; bit-exact with that pipeline's Pillow resampling.
+ *   image_hwc device uint8 [height][width][3]; boxes device int32 [n_views][5] = top, left, h, w, flags
+ *   (crop boxes in source pixels; ttl_amd/views.py draws them like torchvision's RandomResizedCrop, the
+ *   boxes must lie inside the image); flags bit0 = mirror horizontally, bit1 = base view:
+ *   Resize(shorter side -> size, bicubic) over the whole image + CenterCrop(size), box ignored.
+ *   Other views: crop, then bilinear resize to size x size.  out device fp32 [n_views,3,size,size];
+ *   mean/std are HOST pointers to 3 floats; workspace is device scratch of at least
+ *   ttl_make_views_workspace_bytes() bytes (tap tables). */
+size_t ttl_make_views_workspace_bytes(int height, int width, int n_views, int size);
+int ttl_make_views(const unsigned char* image_hwc, int height, int width, const int* boxes, int n_views, int size,
+                   const float mean[3], const float stdv[3], float* out, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* Copy an internal buffer to the host (synchronises): name in {"h_in","h_mid","h_out","qkv",
  * "attn_out","x1","u","lse","dh","features","lora_grads"}; layer indexes encoder layers where it applies. */
 int ttl_debug_copy(ttl_ctx* ctx, const char* name, int layer, void* host_dst, size_t bytes);

@@ -754,6 +754,23 @@ int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const 
     return 0;
 }
 
+size_t ttl_make_views_workspace_bytes(int height, int width, int n_views, int size) {
+    if (height < 1 || width < 1 || n_views < 1 || size < 1) return 0;
+    return (size_t)n_views * 2 * size * views_kstride(height, width, size) * sizeof(int);
+}
+
+int ttl_make_views(const unsigned char* image_hwc, int height, int width, const int* boxes, int n_views, int size,
+                   const float mean[3], const float stdv[3], float* out, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    if (!image_hwc || !boxes || !out || !mean || !stdv || !workspace) return fail(TTL_EINVAL, "null argument");
+    if (height < 1 || width < 1 || n_views < 1 || size < 1) return fail(TTL_EINVAL, "bad shape");
+    if (workspace_bytes < ttl_make_views_workspace_bytes(height, width, n_views, size))
+        return fail(TTL_EINVAL, "workspace smaller than ttl_make_views_workspace_bytes()");
+    HIP_TRY(launch_make_views(image_hwc, height, width, boxes, n_views, size, mean, stdv, out, (int*)workspace,
+                              views_kstride(height, width, size), (hipStream_t)stream));
+    return 0;
+}
+
 int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t bytes) {
     if (!c || !name || !dst) return fail(TTL_EINVAL, "null argument");
     HIP_TRY(hipDeviceSynchronize());

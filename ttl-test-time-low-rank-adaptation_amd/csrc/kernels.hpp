@@ -119,3 +119,10 @@ hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, co
 hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r,
                              float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s);
 int lora_wgrad_chunks(int M);
+
+// ---------------------------------------------------------------- view generator (views.hip)
+// img uint8 HWC [H][W][3]; boxes int32 [n][5] = top,left,height,width,flags (bit0 flip, bit1 base view);
+// out fp32 [n,3,S,S] normalised; table = n*2*S*kstride ints of scratch, kstride = views_kstride(H,W,S).
+int views_kstride(int H, int W, int S);
+hipError_t launch_make_views(const unsigned char* img, int H, int W, const int* boxes, int n, int S, const float* mean,
+                             const float* stdv, float* out, int* table, int kstride, hipStream_t s);

@@ -64,6 +64,8 @@ SIGNATURES = {
     "ttl_cast_f32_operand": (_I, [_P, _P, _Z, _P]),
     "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ttl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ttl_make_views_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "ttl_make_views": (_I, [_P, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _Z, _P]),
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),
     "ttl_profile_enable": (_I, [_P, _I]),
     "ttl_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

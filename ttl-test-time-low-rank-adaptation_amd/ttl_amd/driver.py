@@ -95,7 +95,26 @@ class EpisodePipeline:
                                    stream=torch.cuda.Stream(device=dev),
                                    acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
         self._next = 0
+        self.max_classes = int(text_features.shape[0])
+        self.lora_names = list(lora_names)
         torch.cuda.synchronize(dev)
+
+    def rebind(self, lora_init, text_features, logit_scale_exp):
+        """New dataset on the same frozen weights (the reference loops over set_ids, ttl.py:262-298):
+        fresh class-text features, LoRA snapshot and accuracy accumulators; contexts and arenas stay."""
+        if int(text_features.shape[0]) > self.max_classes:
+            raise ValueError("more classes than the pipeline was built for")
+        self.synchronize()
+        for sl in self.slots:
+            sl["eng"].set_text_features(text_features, logit_scale_exp)
+            flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in self.lora_names]).to(sl["flat"].device)
+            sl["flat"].copy_(flat)
+            sl["snap"].copy_(flat)
+            sl["m"].zero_()
+            sl["v"].zero_()
+            sl["acc"].zero_()
+        self._next = 0
+        torch.cuda.synchronize(self.slots[0]["flat"].device)
 
     def submit(self, views, target=None, **episode_kw):
         """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K].

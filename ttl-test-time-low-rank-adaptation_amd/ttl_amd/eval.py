@@ -13,6 +13,7 @@ rank r takes the items i with i % world == r; ONE all-reduce(SUM) of [hits1, hit
 ends the dataset (RCCL over xGMI on GPUs).
 """
 import argparse
+import itertools
 import json
 import time
 
@@ -32,9 +33,11 @@ def episode_kwargs_from_args(args):
 
 
 def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state, scaler, args, n_streams=2,
-                         rank=0, world=1):
+                         rank=0, world=1, gpu_augmenter=None):
     """Same call shape as ttl.py:300.  ``val_loader`` yields (images, target) with images either a
-    list of [1,3,S,S] tensors (view 0 first, like AugMixAugmenter) or one [N,3,S,S] tensor.
+    list of [1,3,S,S] tensors (view 0 first, like AugMixAugmenter) or one [N,3,S,S] tensor — or, with
+    ``gpu_augmenter`` (views.GpuAugMixAugmenter), one decoded uint8 [H,W,3] image whose views are then
+    generated on the GPU (bit-exact with the host Pillow pipeline for the same crop boxes).
     ``optimizer`` supplies the AdamW hyper-parameters; ``model_state``/``optim_state``/``scaler`` are
     accepted for signature compatibility (the fused episode resets LoRA and Adam state itself).
     Returns [top1, top5] in percent, identical on every rank."""
@@ -46,14 +49,26 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
     kw.update(lr=lr, betas=betas, eps=eps, weight_decay=wd)
     names = [f"p{i}" for i in range(len(model.trainable_lora_parameters()))]
     init = {n: t for n, t in zip(names, _split(model.snapshot_flat(), model.trainable_lora_parameters()))}
-    pipe = EpisodePipeline(model.cfg, model._vision_state, names, init, model.text_features,
-                           float(model.logit_scale.exp()), eng.device, n_streams=n_streams, max_views=eng.max_views,
-                           precision=model.precision)
+    # the slots (contexts, arenas, weight images) outlive one dataset: the reference loops over set_ids
+    # on one model (ttl.py:262-298); only class-text features and the LoRA snapshot change
+    key = (int(n_streams), model.precision, eng.max_views)
+    cache = model.__dict__.setdefault("_episode_pipelines", {})
+    pipe = cache.get(key)
+    if pipe is not None and pipe.max_classes >= model.text_features.shape[0]:
+        pipe.rebind(init, model.text_features, float(model.logit_scale.exp()))
+    else:
+        if pipe is not None:
+            pipe.close()
+        pipe = cache[key] = EpisodePipeline(model.cfg, model._vision_state, names, init, model.text_features,
+                                            float(model.logit_scale.exp()), eng.device, n_streams=n_streams,
+                                            max_views=eng.max_views, precision=model.precision)
     dev = eng.device
     for i, (images, target) in enumerate(val_loader):
         if i % world != rank:
             continue
-        if isinstance(images, (list, tuple)):
+        if gpu_augmenter is not None and torch.is_tensor(images) and images.dtype == torch.uint8:
+            images = gpu_augmenter(images.to(dev, non_blocking=True))                       # datautils.py:141-157 on the GPU
+        elif isinstance(images, (list, tuple)):
             images = torch.cat([im.to(dev, non_blocking=True) for im in images], dim=0)     # ttl.py:324-336
         else:
             images = images.to(dev, non_blocking=True)
@@ -64,7 +79,6 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
     acc = pipe.totals()
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-    pipe.close()
     h1, h5, cnt = (int(v) for v in acc.tolist())
     return [100.0 * h1 / max(cnt, 1), 100.0 * h5 / max(cnt, 1)]
 
@@ -94,6 +108,26 @@ class SyntheticViews:
             yield torch.from_numpy(synth.views(self.cfg, self.v, self.seed * 100003 + i)), i % self.k
 
 
+class SyntheticImages:
+    """Deterministic decoded uint8 [H,W,3] images (ImageNet-like 375x500) for the GPU view generator."""
+
+    def __init__(self, n_items, n_classes, height=375, width=500, seed=0, pool=16):
+        import numpy as np
+        self.n, self.k = n_items, n_classes
+        rng = np.random.default_rng(seed)
+        # a small pool of distinct images in pinned memory, cycled: stands in for a decoded-image queue
+        self.pool = [torch.from_numpy(rng.integers(0, 256, (height, width, 3), dtype=np.uint8)) for _ in range(min(pool, n_items))]
+        if torch.cuda.is_available():
+            self.pool = [t.pin_memory() for t in self.pool]
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield self.pool[i % len(self.pool)], i % self.k
+
+
 def main():
     ap = argparse.ArgumentParser(description="TTL evaluation on synthetic views (no datasets on the GPU box)")
     ap.add_argument("--arch", default="ViT-B/16")
@@ -110,6 +144,7 @@ def main():
     ap.add_argument("--reweight_ent", type=int, default=1)
     ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     a = ap.parse_args()
     a.lora_encoder = "image"
     rank, local, world = dist_env()
@@ -123,14 +158,24 @@ def main():
                                layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier", lora_encoder="image",
                                rank=a.rank, max_views=a.views, max_classes=a.classes, precision=a.precision)
     opt = torch.optim.AdamW([{"params": [p]} for p in model.trainable_lora_parameters()], lr=a.lr)
-    data = SyntheticViews(model.cfg, a.images, a.views, a.classes)
+    aug = None
+    if a.gpu_views:
+        from .views import GpuAugMixAugmenter
+        data = SyntheticImages(a.images, a.classes)
+        aug = GpuAugMixAugmenter(a.views - 1, model.cfg.image_size, precision=a.precision)
+    else:
+        data = SyntheticViews(model.cfg, a.images, a.views, a.classes)
+    # untimed first pass: builds the per-stream contexts (weight images, arenas), like loading the model
+    test_time_adapt_eval(itertools.islice(iter(data), 2 * world), model, None, opt, None, None, a, n_streams=a.streams, rank=rank,
+                         world=world, gpu_augmenter=aug)
     torch.cuda.synchronize()
     t0 = time.time()
-    top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world)
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world,
+                                      gpu_augmenter=aug)
     dt = time.time() - t0
     if rank == 0:
-        print(json.dumps({"top1": top1, "top5": top5, "images": a.images, "world": world,
-                          "images_per_sec_incl_host_view_generation": round(a.images / dt, 2)}))
+        print(json.dumps({"top1": top1, "top5": top5, "images": a.images, "world": world, "gpu_views": bool(a.gpu_views),
+                          "images_per_sec_incl_input_generation": round(a.images / dt, 2)}))
     if world > 1:
         dist.destroy_process_group()
 
