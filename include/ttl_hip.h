@@ -46,9 +46,15 @@ typedef struct ttl_config {
     int layer_lo;     /* first encoder layer whose q/v adapters train */
     int layer_hi;     /* last one (inclusive) */
     float ln_eps;     /* 1e-5 */
-    int max_views;    /* capacity N of one ttl_vit_forward call */
-    int max_classes;  /* capacity K */
+    int max_views;    /* capacity N of one ttl_vit_forward call (text tower: capacity in prompts) */
+    int max_classes;  /* capacity K (text tower: capacity in image views) */
+    int tower;          /* TTL_TOWER_IMAGE (0) or TTL_TOWER_TEXT: the text tower of --lora_encoder text,
+                         * clip/custom_clip.py:602-607 — same encoder layers, causal attention over
+                         * context_length tokens, pooled at the end-of-text token; image_size / patch_size unused */
+    int context_length; /* text tower: 77 */
+    int vocab_size;     /* text tower: 49408 */
 } ttl_config;
+enum { TTL_TOWER_IMAGE = 0, TTL_TOWER_TEXT = 1 };
 
 typedef struct ttl_ctx ttl_ctx;
 
@@ -155,6 +161,28 @@ typedef struct ttl_episode_args {
 } ttl_episode_args;
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
 
+/* ---- --lora_encoder text (clip/custom_clip.py:602-607,615-616,672-678; ttl.py:143-147,190-192) ----
+ * A context created with tower = TTL_TOWER_TEXT holds the HF text tower ("text_model.embeddings.token_embedding.weight",
+ * "text_model.embeddings.position_embedding.weight", "text_model.encoder.layers.{i}.*", "text_model.final_layer_norm.*",
+ * "text_projection.weight" through ttl_load_weight) and its q/v LoRA (ttl_bind_lora, same layout).  The image tower runs
+ * on a second, ordinary context WITHOUT ttl_bind_lora (no adapters exist on it in this mode) and only supplies features. */
+/* exp(logit_scale) used by the text context's logits. */
+int ttl_set_logit_scale(ttl_ctx* text_ctx, float logit_scale_exp);
+/* prompt_learner.tokenized_prompts (clip/custom_clip.py:655): ids int32 [n_prompts][context_length], host or device.
+ * The pooled position of a prompt is the argmax of its ids (end-of-text), like HF CLIPTextTransformer.  Synchronises. */
+int ttl_set_prompts(ttl_ctx* text_ctx, const int* ids, int n_prompts, void* stream);
+/* Image features of the current views [n_views,E] (device), L2-normalised on the way in when normalize != 0
+ * (clip/custom_clip.py:680); asynchronous. */
+int ttl_set_image_features(ttl_ctx* text_ctx, const float* feats, int n_views, int normalize, float logit_scale_exp, void* stream);
+/* get_text_features with grad (clip/custom_clip.py:651-663,677-678) + logits: logits_out [n_views,n_prompts] or NULL,
+ * feats_out un-normalised text features [n_prompts,E] or NULL. */
+int ttl_text_forward(ttl_ctx* text_ctx, int save_for_backward, float* logits_out, float* feats_out, void* stream);
+/* dlogits [n_views,n_prompts] -> gradients of the bound text LoRA buffer. */
+int ttl_text_backward_lora(ttl_ctx* text_ctx, const float* dlogits, void* stream);
+/* Whole per-image episode in text mode: image features of args->x on image_ctx (no grad), then
+ * n_updates x [text forward, loss, text LoRA backward, AdamW], then the adapted logits of view 0. */
+int ttl_episode_text(ttl_ctx* text_ctx, ttl_ctx* image_ctx, const ttl_episode_args* args, void* stream);
+
 /* ---- kernel-level entry points (used by the unit parity tests; same kernels as above) ---- */
 /* C[M,N] = A[M,K](operand dtype, lda) * B[N,K]^T(operand dtype, ldb) -> fp32 C (ldc).  K % 64 == 0, N % 128 == 0. */
 int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
@@ -165,12 +193,12 @@ int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, flo
 /* fp32 -> operand dtype (round to nearest even). */
 int ttl_cast_f32_operand(const float* src, void* dst, size_t n, void* stream);
 /* softmax(q k^T / 8) v for head dim 64: qkv (operand dtype) [n*T, 3*H*64] (q | k | v), out [n*T, H*64],
- * lse fp32 [n,H,T] or NULL. */
+ * lse fp32 [n,H,T] or NULL; causal != 0 masks keys after the query (text tower). */
 int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n_views, int tokens, int heads,
-                      void* stream);
+                      int causal, void* stream);
 /* dq,dk,dv of the above: dqkv (operand dtype) [n*T, ld_dqkv] (dq | dk | dv); need_dk == 0 skips dk. */
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                      int ld_dqkv, int n_views, int tokens, int heads, int need_dk, void* stream);
+                      int ld_dqkv, int n_views, int tokens, int heads, int need_dk, int causal, void* stream);
 
 /* GPU-side view generator: replaces the host pipeline data/datautils.py:98-157 with aug_list = [] (Q13)
  * and ToTensor + Normalize of ttl.py:225-241; bit-exact with that pipeline's Pillow resampling.

@@ -214,16 +214,19 @@ class VitOracle:
     ``lora``: dict name -> array for layers.{i}.self_attn.{q,v}_proj.lora_{A,B}.default.weight.
     """
 
+    tower = "vision_model"      # HF sub-module the layer names hang off
+    causal = False              # text tower: causal mask (modeling_clip.py CLIPTextTransformer)
+
     def __init__(self, cfg, W, lora, prec="fp32"):
         self.cfg, self.W, self.lora, self.prec = cfg, W, lora, prec
         self.r = _rounder(prec)
 
     # -- parameter access
     def _lw(self, i, name):
-        return self.W[f"vision_model.encoder.layers.{i}.{name}"]
+        return self.W[f"{self.tower}.encoder.layers.{i}.{name}"]
 
     def _lora(self, i, proj, ab):
-        return self.lora[f"vision_model.encoder.layers.{i}.self_attn.{proj}.lora_{ab}.default.weight"]
+        return self.lora[f"{self.tower}.encoder.layers.{i}.self_attn.{proj}.lora_{ab}.default.weight"]
 
     def trained(self, i):
         return self.cfg.layer_lo <= i <= self.cfg.layer_hi
@@ -261,6 +264,8 @@ class VitOracle:
         k = qkv["k_proj"].reshape(N, T, Hh, dh).transpose(0, 2, 1, 3)
         v = qkv["v_proj"].reshape(N, T, Hh, dh).transpose(0, 2, 1, 3)
         sc = (q @ k.transpose(0, 1, 3, 2)) * np.float32(dh ** -0.5)
+        if self.causal:
+            sc = np.where(np.tril(np.ones((T, T), bool)), sc, np.float32(-np.inf))
         mx = sc.max(-1, keepdims=True)
         e = np.exp(sc - mx)
         den = e.sum(-1, keepdims=True)
@@ -315,11 +320,9 @@ class VitOracle:
     # -- backward (truncated at the first trained layer)
     def backward(self, dz, tfeat, save):
         """dL/dlogits [N,K] -> dict of LoRA grads keyed like ``lora``."""
-        c, r = self.cfg, self.r
+        c = self.cfg
         hd = save["head"]
         N = dz.shape[0]
-        T, D, Hh, dhd = c.tokens, c.width, c.heads, c.head_dim
-        s = np.float32(c.scaling)
         S = np.float32(np.exp(self.W["logit_scale"]))
         f = hd["f"]
         nrm = np.linalg.norm(f, axis=-1, keepdims=True)
@@ -328,8 +331,16 @@ class VitOracle:
         df = (dfh - fh * (fh * dfh).sum(-1, keepdims=True)) / nrm
         dy = df @ self.W["visual_projection.weight"]
         dcls = layer_norm_bwd(dy, hd["cls"], hd["mu"], hd["rs"], self.W["vision_model.post_layernorm.weight"])
-        dh = np.zeros((N, T, D), np.float32)
+        dh = np.zeros((N, c.tokens, c.width), np.float32)
         dh[:, 0, :] = dcls
+        return self.backward_layers(dh, save)
+
+    def backward_layers(self, dh, save):
+        """d/d(residual stream after the last layer) [N,T,D] -> LoRA grads of the trained layers."""
+        c, r = self.cfg, self.r
+        N = dh.shape[0]
+        T, D, Hh, dhd = c.tokens, c.width, c.heads, c.head_dim
+        s = np.float32(c.scaling)
         grads = {}
         for i in range(c.layer_hi, c.layer_lo - 1, -1):
             sv = save[i]
@@ -344,6 +355,8 @@ class VitOracle:
             dO = do.reshape(N, T, Hh, dhd).transpose(0, 2, 1, 3)
             q, k, v = sv["q"], sv["k"], sv["v"]
             sc = (q @ k.transpose(0, 1, 3, 2)) * np.float32(dhd ** -0.5)
+            if self.causal:
+                sc = np.where(np.tril(np.ones((T, T), bool)), sc, np.float32(-np.inf))
             Pm = np.exp(sc - sv["lse"][..., None])
             O = sv["o"].reshape(N, T, Hh, dhd).transpose(0, 2, 1, 3)
             delta = (dO * O).sum(-1, keepdims=True)
@@ -354,7 +367,7 @@ class VitOracle:
             merge = lambda a: r(a.transpose(0, 2, 1, 3).reshape(N * T, D).astype(np.float32))
             dq, dv = merge(dQ), merge(dV)
             x1 = sv["x1"].reshape(N * T, D)
-            base = f"vision_model.encoder.layers.{i}.self_attn."
+            base = f"{self.tower}.encoder.layers.{i}.self_attn."
             dU = {}
             for pj, dproj in (("q_proj", dq), ("v_proj", dv)):
                 A, B = self._lora(i, pj, "A"), self._lora(i, pj, "B")
@@ -375,15 +388,110 @@ class VitOracle:
         return grads
 
 
+# ------------------------------------------------------------------------- text tower
+class TextOracle(VitOracle):
+    """HF CLIP text tower + text_projection with LoRA on q_proj/v_proj (``--lora_encoder text``,
+    clip/custom_clip.py:602-607,672-678; HF modeling_clip.py CLIPTextTransformer: token + position
+    embeddings, causal pre-LN encoder, final_layer_norm, pooled at argmax(input_ids) — the eot token,
+    legacy eos_token_id == 2 branch — then text_projection without bias).  ``cfg``: config.TextConfig."""
+    tower = "text_model"
+    causal = True
+
+    def forward(self, ids, save=None, taps=None):
+        """ids [K,T] int -> text features t [K,E] (un-normalised)."""
+        c = self.cfg
+        ids = np.asarray(ids)
+        h = (self.W["text_model.embeddings.token_embedding.weight"][ids]
+             + self.W["text_model.embeddings.position_embedding.weight"][None, :ids.shape[1]]).astype(np.float32)
+        if taps is not None:
+            taps["embed"] = h
+        for i in range(c.layers):
+            h = self.layer_forward(i, h, save)
+            if taps is not None:
+                taps[f"layer{i}"] = h
+        eot = ids.argmax(-1)
+        pooled = h[np.arange(ids.shape[0]), eot, :]
+        y, mu, rs = layer_norm(pooled, self.W["text_model.final_layer_norm.weight"],
+                               self.W["text_model.final_layer_norm.bias"], c.ln_eps)
+        t = (y @ self.W["text_projection.weight"].T).astype(np.float32)
+        if save is not None:
+            save["head"] = dict(cls=pooled, mu=mu, rs=rs, y=y, f=t, eot=eot)
+        if taps is not None:
+            taps["pooled"] = y
+            taps["features"] = t
+        return t
+
+    def backward(self, dz, fh_img, save, logit_scale_exp):
+        """dL/dlogits [N,K] with logits = S * fh_img @ that^T  ->  text LoRA grads."""
+        c = self.cfg
+        hd = save["head"]
+        t = hd["f"]
+        nrm = np.linalg.norm(t, axis=-1, keepdims=True)
+        th = t / nrm
+        dth = np.float32(logit_scale_exp) * (dz.T @ fh_img)                     # [K,E]
+        dt = (dth - th * (th * dth).sum(-1, keepdims=True)) / nrm
+        dy = dt @ self.W["text_projection.weight"]
+        dpool = layer_norm_bwd(dy, hd["cls"], hd["mu"], hd["rs"], self.W["text_model.final_layer_norm.weight"])
+        K = dz.shape[1]
+        dh = np.zeros((K, c.tokens, c.width), np.float32)
+        dh[np.arange(K), hd["eot"], :] = dpool
+        return self.backward_layers(dh, save)
+
+
 # ---------------------------------------------------------------------------- episode
-def trainable_names(cfg):
+def trainable_names(cfg, tower="vision_model"):
     """Order of the 12 param groups at ttl.py:195-213: per layer q.A, q.B, v.A, v.B."""
     out = []
     for i in range(cfg.layer_lo, cfg.layer_hi + 1):
         for pj in ("q_proj", "v_proj"):
             for ab in ("A", "B"):
-                out.append(f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight")
+                out.append(f"{tower}.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight")
     return out
+
+
+def episode_text(vcfg, tcfg, Wv, Wt, lora0, x, ids, *, prec="fp32", objective="deyo", mode="le_thresh",
+                 rho=0.1, margin=0.4, reweight=1.0, n_updates=1, lr=5e-3, betas=(0.9, 0.999),
+                 eps=1e-8, wd=1e-2, trace=None):
+    """``--lora_encoder text`` episode (clip/custom_clip.py:665-703 with lora_encoder == 'text'):
+    image features of the N views without grad (no LoRA on the image tower), text features of the K
+    prompts with grad through the text-tower LoRA, same loss / AdamW / adapted inference on view 0."""
+    lora = {k: v.copy() for k, v in lora0.items()}
+    names = trainable_names(tcfg, "text_model")
+    m = {k: np.zeros_like(lora[k]) for k in names}
+    v = {k: np.zeros_like(lora[k]) for k in names}
+    vis = VitOracle(vcfg, Wv, {}, prec)
+    vis.trained = lambda i: False                          # the image tower carries no adapters in this mode
+    f = vis.forward(x)
+    fh = (f / np.linalg.norm(f, axis=-1, keepdims=True)).astype(np.float32)
+    S = np.float32(np.exp(Wv["logit_scale"]))
+    t_step, logits0, tpt_idx = 0, None, None
+    for _ in range(n_updates):
+        net = TextOracle(tcfg, Wt, lora, prec)
+        save = {}
+        t = net.forward(ids, save)
+        th = t / np.linalg.norm(t, axis=-1, keepdims=True)
+        z = (S * fh @ th.T).astype(np.float32)
+        if logits0 is None:
+            logits0 = z
+        if objective == "deyo":
+            L = deyo_loss_and_grad(z, mode, rho, margin, reweight)
+        else:
+            L = tpt_loss_and_grad(z, tpt_idx, rho)
+            tpt_idx = L["idx"]
+        rec = dict(logits=z, H=L["H"], idx=L["idx"], loss=L["loss"])
+        if L["loss"] is not None:
+            grads = net.backward(L["dz"], fh, save, S)
+            t_step += 1
+            for k in names:
+                lora[k], m[k], v[k] = adamw_step(lora[k], grads[k], m[k], v[k], t_step, lr, betas[0], betas[1], eps, wd)
+            rec["grads"] = grads
+        if trace is not None:
+            trace.append(rec)
+    net = TextOracle(tcfg, Wt, lora, prec)
+    t = net.forward(ids)
+    th = t / np.linalg.norm(t, axis=-1, keepdims=True)
+    z1 = (S * fh[:1] @ th.T).astype(np.float32)
+    return dict(logits0=logits0, logits1=z1, lora=lora, image_features=fh, text_features=th.astype(np.float32))
 
 
 def episode(cfg, W, lora0, x, tfeat, *, prec="fp32", objective="deyo", mode="le_thresh",

@@ -121,11 +121,40 @@ def install_import_stubs():
          TaskType=types.SimpleNamespace())
 
 
-def make_clip_model(cfg, seed, text_seed=1234):
-    """HF CLIPModel of geometry ``cfg`` with the synthetic vision weights loaded."""
+def make_clip_model(cfg, seed, text_seed=1234, text_cfg=None):
+    """HF CLIPModel of geometry ``cfg`` with the synthetic vision weights loaded.  With ``text_cfg``
+    (config.TextConfig; the --lora_encoder text fixtures) the text tower has that geometry and carries
+    ttl_amd.synth.text_weights(text_cfg, seed); without it, a small seeded random text tower (the image-
+    mode fixtures only store its output features)."""
     from transformers import CLIPConfig, CLIPModel
     from ttl_amd import synth
     torch.manual_seed(text_seed)
+    if text_cfg is not None:
+        conf = CLIPConfig(
+            vision_config=dict(hidden_size=cfg.width, intermediate_size=cfg.mlp,
+                               num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                               image_size=cfg.image_size, patch_size=cfg.patch_size,
+                               hidden_act="quick_gelu", layer_norm_eps=cfg.ln_eps,
+                               projection_dim=cfg.embed),
+            text_config=dict(hidden_size=text_cfg.width, intermediate_size=text_cfg.mlp,
+                             num_hidden_layers=text_cfg.layers, num_attention_heads=text_cfg.heads,
+                             eos_token_id=2, vocab_size=text_cfg.vocab_size, hidden_act="quick_gelu",
+                             max_position_embeddings=text_cfg.context_length, layer_norm_eps=text_cfg.ln_eps,
+                             projection_dim=text_cfg.embed),
+            projection_dim=cfg.embed)
+        conf._attn_implementation = "eager"
+        model = CLIPModel(conf).float().eval()
+        W = dict(synth.vision_weights(cfg, seed))
+        W.update(synth.text_weights(text_cfg, seed))
+        sd = model.state_dict()
+        for k, a in W.items():
+            assert k in sd and tuple(sd[k].shape) == a.shape, (k, a.shape)
+            sd[k].copy_(torch.from_numpy(a))
+        model.load_state_dict(sd)
+        gi, gt = model.get_image_features, model.get_text_features
+        model.get_image_features = lambda *a, **k: _unwrap(gi(*a, **k))
+        model.get_text_features = lambda *a, **k: _unwrap(gt(*a, **k))
+        return model
     text_w = 64 if cfg.width <= 128 else 512
     conf = CLIPConfig(
         vision_config=dict(hidden_size=cfg.width, intermediate_size=cfg.mlp,
@@ -175,8 +204,8 @@ class _FakeOpenAIClip(nn.Module):
         self.dtype = torch.float32
 
 
-def import_reference(cfg, seed):
-    """Returns (ttl, deyo, custom_clip) reference modules, patched to build ``cfg``."""
+def import_reference(cfg, seed, text_cfg=None):
+    """Returns (ttl, deyo, custom_clip) reference modules, patched to build ``cfg`` (+ ``text_cfg``)."""
     install_import_stubs()
     if REF not in sys.path:
         sys.path.insert(0, REF)
@@ -195,5 +224,5 @@ def import_reference(cfg, seed):
         m.load = fake_load
     from transformers import CLIPModel
     ref_cc.CLIPModel = type("PatchedCLIPModel", (), {
-        "from_pretrained": staticmethod(lambda *a, **k: make_clip_model(cfg, seed))})
+        "from_pretrained": staticmethod(lambda *a, **k: make_clip_model(cfg, seed, text_cfg=text_cfg))})
     return ref_ttl, ref_deyo, ref_cc

@@ -62,3 +62,22 @@ def check_lora_step(new, ref, grad, lr, tol, name="", dg=None, eps=1e-8):
     err = np.abs(new - ref)
     bad = err > allowed
     assert not bad.any(), (name, int(bad.sum()), float((err - allowed).max()))
+
+
+def load_text_case(name):
+    """--lora_encoder text fixtures -> (golden npz, vcfg, tcfg, Wv, Wt, x, ids, lora0) rebuilt from seeds."""
+    from ttl_amd.config import get_text_config
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    arch = str(g["arch"])
+    vcfg, tcfg = get_config(arch), get_text_config(arch)
+    Wv = synth.vision_weights(vcfg, int(g["weight_seed"]))
+    assert synth.checksum(Wv) == str(g["weights_sha256"]), "synthetic weights drifted from the fixture"
+    Wt = synth.text_weights(tcfg, int(g["weight_seed"]))
+    x = synth.views(vcfg, int(g["n_views"]), int(g["view_seed"]))
+    ids = g["ids"]
+    assert np.array_equal(ids, synth.token_ids(int(g["n_classes"]), tcfg, int(g["ids_seed"])))
+    lora0 = synth.lora_init(tcfg, 0, tower="text_model")
+    for k in g.files:
+        if k.startswith("lora0/"):
+            lora0[k[6:]] = g[k]
+    return g, vcfg, tcfg, Wv, Wt, x, ids, lora0

@@ -81,11 +81,13 @@ def test_layernorm(lib, rows, D):
     assert max_rel(rs.cpu().numpy(), rrs[:, 0]) < 1e-5
 
 
-def _attn_ref(qkv, n, T, H):
+def _attn_ref(qkv, n, T, H, causal=0):
     D = H * 64
     x = qkv.reshape(n, T, 3, H, 64).transpose(2, 0, 3, 1, 4)        # [3,n,H,T,64]
     q, k, v = x[0], x[1], x[2]
     s = (q @ k.transpose(0, 1, 3, 2)) * 0.125
+    if causal:
+        s = np.where(np.tril(np.ones((T, T), bool)), s, -np.inf)
     m = s.max(-1, keepdims=True)
     e = np.exp(s - m)
     den = e.sum(-1, keepdims=True)
@@ -94,19 +96,20 @@ def _attn_ref(qkv, n, T, H):
     return q, k, v, p, o, (m + np.log(den))[..., 0]
 
 
-@pytest.mark.parametrize("n,T,H", [(2, 17, 2), (3, 197, 2), (1, 257, 4), (2, 50, 12), (1, 150, 1)])
-def test_attention_fwd_bwd(lib, n, T, H):
+@pytest.mark.parametrize("n,T,H,causal", [(2, 17, 2, 0), (3, 197, 2, 0), (1, 257, 4, 0), (2, 50, 12, 0), (1, 150, 1, 0),
+                                          (3, 77, 8, 1), (2, 77, 2, 1), (2, 17, 2, 1), (1, 197, 2, 1)])
+def test_attention_fwd_bwd(lib, n, T, H, causal):
     D = H * 64
     g = torch.Generator().manual_seed(T)
     qkv = (torch.randn(n * T, 3 * D, generator=g)).to(torch.bfloat16)
     qkv[:, :D] *= 1.5
     dout = (torch.randn(n * T, D, generator=g) * 0.1).to(torch.bfloat16)
-    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H)
+    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, causal)
     out = torch.full((n * T, D), float("nan"), device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(n, H, T, device="cuda")
     dq = qkv.cuda()
     ddo = dout.cuda()
-    chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse), n, T, H, S()))
+    chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse), n, T, H, causal, S()))
     torch.cuda.synchronize()
     o_ref = o.transpose(0, 2, 1, 3).reshape(n * T, D)
     assert max_rel(out.float().cpu().numpy(), o_ref) < 6e-3          # bf16 output rounding
@@ -124,7 +127,7 @@ def test_attention_fwd_bwd(lib, n, T, H):
     ld = 3 * D + 64
     for need_dk in (1, 0):
         dqkv = torch.zeros(n * T, ld, device="cuda", dtype=torch.bfloat16)
-        chk(lib, lib.ttl_attention_bwd(P(dq), P(out), P(ddo), P(lse), P(dqkv), ld, n, T, H, need_dk, S()))
+        chk(lib, lib.ttl_attention_bwd(P(dq), P(out), P(ddo), P(lse), P(dqkv), ld, n, T, H, need_dk, causal, S()))
         torch.cuda.synchronize()
         r = dqkv.float().cpu().numpy()
         assert max_rel(r[:, :D], mg(dQ)) < 1e-2

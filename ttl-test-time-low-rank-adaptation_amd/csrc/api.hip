@@ -81,7 +81,13 @@ struct ttl_ctx {
     float *cls, *pos, *preg, *preb, *postg, *postb;
     float *wp, *wpT;  // [E][D], [D][E]
     unsigned head_loaded = 0;
-    // text side
+    // text tower (c.tower == TTL_TOWER_TEXT): token table, prompt ids, pooled (end-of-text) positions and the
+    // compact copies of the pooled rows the top-layer backward reads; logits in [views, prompts] order
+    int text = 0;
+    float* tok = nullptr; int* ids = nullptr; int* pool = nullptr; int n_prompts = 0;
+    float *hpool = nullptr, *hmid_g = nullptr, *mu2_g = nullptr, *rs2_g = nullptr; op_t* u_g = nullptr;
+    float *logits_nk = nullptr, *dlogits_nk = nullptr, *dlogits_kn = nullptr;
+    // peer features (image tower: class-text features; text tower: the image features of the views)
     float *tfeat, *tfeatT;
     int K = 0;
     float scale = 100.f;
@@ -135,12 +141,16 @@ int check_config(const ttl_config* k) {
         return fail(TTL_EINVAL, "width must be a multiple of 128 with head_dim 64 (got D=%d H=%d)", k->width, k->heads);
     if (k->mlp % 128) return fail(TTL_EINVAL, "mlp must be a multiple of 128");
     if (k->rank != 16 && k->rank != 32) return fail(TTL_EINVAL, "rank must be 16 or 32 (got %d)", k->rank);
-    if (k->image_size % k->patch_size || k->image_size % 8) return fail(TTL_EINVAL, "bad image/patch size");
+    if (k->tower != TTL_TOWER_IMAGE && k->tower != TTL_TOWER_TEXT) return fail(TTL_EINVAL, "unknown tower %d", k->tower);
+    if (k->tower == TTL_TOWER_TEXT) {
+        if (k->context_length < 2 || k->context_length > 128 || k->vocab_size < 2)
+            return fail(TTL_EINVAL, "bad context_length %d / vocab_size %d", k->context_length, k->vocab_size);
+    } else if (k->patch_size < 1 || k->image_size % k->patch_size || k->image_size % 8) return fail(TTL_EINVAL, "bad image/patch size");
     if (k->layer_lo < 0 || k->layer_hi >= k->layers || k->layer_lo > k->layer_hi || k->layer_hi - k->layer_lo >= 8)
         return fail(TTL_EINVAL, "bad layer range [%d,%d]", k->layer_lo, k->layer_hi);
     if (k->layer_hi != k->layers - 1)
         return fail(TTL_EINVAL, "layer_hi must be the last encoder layer (%d); got %d", k->layers - 1, k->layer_hi);
-    int T = (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
+    int T = k->tower == TTL_TOWER_TEXT ? k->context_length : (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
     if (T > 288) return fail(TTL_EINVAL, "token count %d > 288 unsupported", T);
     if (k->max_views < 1 || k->max_classes < 1 || k->embed < 1 || k->embed > 4096) return fail(TTL_EINVAL, "bad capacities");
     return 0;
@@ -149,8 +159,10 @@ int check_config(const ttl_config* k) {
 void set_geometry(ttl_ctx* c, const ttl_config* k) {
     c->c = *k;
     c->D = k->width; c->F = k->mlp; c->H = k->heads; c->E = k->embed; c->L = k->layers; c->P = k->patch_size;
-    c->S = k->image_size; c->G2 = (c->S / c->P) * (c->S / c->P); c->T = c->G2 + 1; c->r = k->rank;
-    c->Kp = round_up(3 * c->P * c->P, 64);
+    c->text = (k->tower == TTL_TOWER_TEXT);
+    c->S = k->image_size; c->r = k->rank;
+    if (c->text) { c->G2 = 0; c->T = k->context_length; c->Kp = 64; }
+    else { c->G2 = (c->S / c->P) * (c->S / c->P); c->T = c->G2 + 1; c->Kp = round_up(3 * c->P * c->P, 64); }
     c->ldx = c->D + 64;        // x1ext: D | 2r LoRA cols | zero pad
     c->ldw = c->D + 64;        // wqkv rows
     c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
@@ -182,7 +194,8 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
 
 enum { W_QW = 1, W_QB = 2, W_KW = 4, W_KB = 8, W_VW = 16, W_VB = 32, W_OW = 64, W_OB = 128, W_1W = 256, W_1B = 512,
        W_2W = 1024, W_2B = 2048, W_L1G = 4096, W_L1B = 8192, W_L2G = 16384, W_L2B = 32768, W_ALL = 65535 };
-enum { HW_CLS = 1, HW_PATCH = 2, HW_POS = 4, HW_PREG = 8, HW_PREB = 16, HW_POSTG = 32, HW_POSTB = 64, HW_PROJ = 128, HW_ALL = 255 };
+enum { HW_CLS = 1, HW_PATCH = 2, HW_POS = 4, HW_PREG = 8, HW_PREB = 16, HW_POSTG = 32, HW_POSTB = 64, HW_PROJ = 128, HW_ALL = 255,
+       HW_TOK = 256, HW_TEXT_ALL = HW_TOK | HW_POS | HW_POSTG | HW_POSTB | HW_PROJ };
 
 }  // namespace
 
@@ -197,7 +210,8 @@ size_t ttl_workspace_bytes(const ttl_config* k) {
     if (check_config(k)) return 0;
     ttl_ctx t; set_geometry(&t, k);
     size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nT, N = k->max_views;
-    size_t w = L * (3 * D * t.ldw + D * D + 2 * D * F) * 2 + nT * (D * t.ldwt + D * D + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4;
+    size_t w = L * (3 * D * t.ldw + D * D + 2 * D * F) * 2 + nT * (D * t.ldwt + D * D + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
+               (t.text ? (size_t)k->vocab_size * D * 4 : 0);
     size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * D + M * F) * 2 +
                  (M * D + M * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * D + M * F + M * D + M * t.ldwt) * 2 +
                  (size_t)lora_wgrad_chunks((int)M) * 4 * t.r * D * 4;
@@ -236,6 +250,14 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
         }
     }
     ALLOC(c->wpatch, D * c->Kp, true);
+    if (c->text) {
+        ALLOC(c->tok, (size_t)k->vocab_size * D, false);
+        ALLOC(c->ids, N * T, true); ALLOC(c->pool, N, true);
+        ALLOC(c->hpool, N * D, true); ALLOC(c->hmid_g, N * D, false); ALLOC(c->mu2_g, N, false); ALLOC(c->rs2_g, N, false);
+        ALLOC(c->u_g, N * F, false);
+        ALLOC(c->logits_nk, N * k->max_classes, false); ALLOC(c->dlogits_nk, N * k->max_classes, false);
+        ALLOC(c->dlogits_kn, N * k->max_classes, false);
+    }
     ALLOC(c->cls, D, true); ALLOC(c->pos, T * D, true);
     ALLOC(c->preg, D, true); ALLOC(c->preb, D, true); ALLOC(c->postg, D, true); ALLOC(c->postb, D, true);
     ALLOC(c->wp, E * D, true); ALLOC(c->wpT, D * E, true);
@@ -256,8 +278,10 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 4 * r * D, false);
     c->gemm_ws_bytes = (size_t)8 << 20;
     ALLOC(c->gemm_ws, c->gemm_ws_bytes / sizeof(float), false);
-    ALLOC(c->loss_scratch, 4 * N + 3 * (size_t)k->max_classes + 16, true);
-    ALLOC(c->idx_buf, N, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, N, true);
+    // (the text tower runs the loss on [views, prompts] logits: either count can be the larger one)
+    const size_t nmax = N > (size_t)k->max_classes ? N : (size_t)k->max_classes;
+    ALLOC(c->loss_scratch, 7 * nmax + 16, true);
+    ALLOC(c->idx_buf, nmax, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, nmax, true);
     guard.ok = true;
     *out = c;
     return 0;
@@ -341,6 +365,13 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
         if (t == "layer_norm2.bias") { NEED(D); F32COPY(l.ln2b); l.loaded |= W_L2B; return 0; }
         return fail(TTL_EINVAL, "unknown layer tensor %s", name);
     }
+    if (c->text) {
+        if (nm == "text_model.embeddings.token_embedding.weight") { NEED((size_t)c->c.vocab_size * D); F32COPY(c->tok); c->head_loaded |= HW_TOK; return 0; }
+        if (nm == "text_model.embeddings.position_embedding.weight") { NEED(T * D); F32COPY(c->pos); c->head_loaded |= HW_POS; return 0; }
+        if (nm == "text_model.final_layer_norm.weight") { NEED(D); F32COPY(c->postg); c->head_loaded |= HW_POSTG; return 0; }
+        if (nm == "text_model.final_layer_norm.bias") { NEED(D); F32COPY(c->postb); c->head_loaded |= HW_POSTB; return 0; }
+        if (nm != "text_projection.weight") return fail(TTL_EINVAL, "unknown text-tower tensor %s", name);
+    }
     if (nm == "vision_model.embeddings.class_embedding") { NEED(D); F32COPY(c->cls); c->head_loaded |= HW_CLS; return 0; }
     if (nm == "vision_model.embeddings.position_embedding.weight") { NEED(T * D); F32COPY(c->pos); c->head_loaded |= HW_POS; return 0; }
     if (nm == "vision_model.embeddings.patch_embedding.weight") {
@@ -358,7 +389,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
     if (nm == "vision_model.pre_layrnorm.bias") { NEED(D); F32COPY(c->preb); c->head_loaded |= HW_PREB; return 0; }
     if (nm == "vision_model.post_layernorm.weight") { NEED(D); F32COPY(c->postg); c->head_loaded |= HW_POSTG; return 0; }
     if (nm == "vision_model.post_layernorm.bias") { NEED(D); F32COPY(c->postb); c->head_loaded |= HW_POSTB; return 0; }
-    if (nm == "visual_projection.weight") {
+    if (nm == (c->text ? "text_projection.weight" : "visual_projection.weight")) {
         NEED(E * D);
         F32COPY(c->wp);
         std::vector<float> host(count), tr(count);
@@ -376,26 +407,64 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
 
 int ttl_weights_ready(ttl_ctx* c) {
     if (!c) return fail(TTL_EINVAL, "null ctx");
-    if (c->head_loaded != HW_ALL) return fail(TTL_ESTATE, "embedding/head tensors missing (mask 0x%x of 0x%x)", c->head_loaded, HW_ALL);
+    const unsigned want = c->text ? (unsigned)HW_TEXT_ALL : (unsigned)HW_ALL;
+    if (c->head_loaded != want) return fail(TTL_ESTATE, "embedding/head tensors missing (mask 0x%x of 0x%x)", c->head_loaded, want);
     for (int i = 0; i < c->L; ++i)
         if (c->layers[i].loaded != W_ALL) return fail(TTL_ESTATE, "layer %d tensors missing (mask 0x%x)", i, c->layers[i].loaded);
     return 0;
 }
 
-int ttl_set_text_features(ttl_ctx* c, const float* tfeat, int K, float scale, void* stream) {
-    if (!c || !tfeat) return fail(TTL_EINVAL, "null argument");
-    if (K < 1 || K > c->c.max_classes) return fail(TTL_EINVAL, "n_classes %d outside [1,%d]", K, c->c.max_classes);
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(c->tfeat, tfeat, (size_t)K * c->E * sizeof(float), hipMemcpyDefault, s));
-    // transposed copy [E][K] for coalesced logits; small, do it through the host once per dataset
-    std::vector<float> host((size_t)K * c->E), tr((size_t)K * c->E);
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(host.data(), c->tfeat, host.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (int k = 0; k < K; ++k)
-        for (int e = 0; e < c->E; ++e) tr[(size_t)e * K + k] = host[(size_t)k * c->E + e];
-    HIP_TRY(hipMemcpy(c->tfeatT, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+// peer features [K,E] (+ transposed copy [E,K] for coalesced logits), optionally L2-normalised on the way in
+static int set_peer_features(ttl_ctx* c, const float* feats, int K, int normalize, float scale, hipStream_t s) {
+    if (K < 1 || K > c->c.max_classes) return fail(TTL_EINVAL, "feature rows %d outside [1,%d]", K, c->c.max_classes);
+    // tfeat doubles as the staging buffer: copy in, then normalise / transpose out of it in place (row-wise safe)
+    HIP_TRY(hipMemcpyAsync(c->tfeat, feats, (size_t)K * c->E * sizeof(float), hipMemcpyDefault, s));
+    HIP_TRY(launch_unit_rows(c->tfeat, K, c->E, normalize, c->tfeat, c->tfeatT, s));
     c->K = K;
     c->scale = scale;
+    return 0;
+}
+
+int ttl_set_text_features(ttl_ctx* c, const float* tfeat, int K, float scale, void* stream) {
+    if (!c || !tfeat) return fail(TTL_EINVAL, "null argument");
+    if (c->text) return fail(TTL_ESTATE, "ttl_set_text_features on a text-tower context (use ttl_set_image_features)");
+    return set_peer_features(c, tfeat, K, 0, scale, (hipStream_t)stream);
+}
+
+int ttl_set_image_features(ttl_ctx* c, const float* feats, int n_views, int normalize, float scale, void* stream) {
+    if (!c || !feats) return fail(TTL_EINVAL, "null argument");
+    if (!c->text) return fail(TTL_ESTATE, "ttl_set_image_features needs a text-tower context");
+    return set_peer_features(c, feats, n_views, normalize, scale, (hipStream_t)stream);
+}
+
+int ttl_set_logit_scale(ttl_ctx* c, float logit_scale_exp) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    c->scale = logit_scale_exp;
+    return 0;
+}
+
+int ttl_set_prompts(ttl_ctx* c, const int* ids, int n_prompts, void* stream) {
+    if (!c || !ids) return fail(TTL_EINVAL, "null argument");
+    if (!c->text) return fail(TTL_ESTATE, "ttl_set_prompts needs a text-tower context");
+    if (n_prompts < 1 || n_prompts > c->c.max_views) return fail(TTL_EINVAL, "n_prompts %d outside [1,%d]", n_prompts, c->c.max_views);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cnt = (size_t)n_prompts * c->T;
+    std::vector<int> host(cnt), pool(n_prompts);
+    HIP_TRY(hipMemcpy(host.data(), ids, cnt * sizeof(int), hipMemcpyDefault));
+    for (int p = 0; p < n_prompts; ++p) {
+        // pooled position = argmax of the ids (first maximum), HF CLIPTextTransformer with eos_token_id == 2
+        int best = 0;
+        for (int t = 0; t < c->T; ++t) {
+            int v = host[(size_t)p * c->T + t];
+            if (v < 0 || v >= c->c.vocab_size) return fail(TTL_EINVAL, "token id %d outside the vocabulary (prompt %d, position %d)", v, p, t);
+            if (v > host[(size_t)p * c->T + best]) best = t;
+        }
+        pool[p] = best;
+    }
+    HIP_TRY(hipMemcpyAsync(c->ids, host.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->pool, pool.data(), n_prompts * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // the host vectors go out of scope
+    c->n_prompts = n_prompts;
     return 0;
 }
 
@@ -410,7 +479,7 @@ int ttl_bind_lora(ttl_ctx* c, float* params, float* grads, size_t n) {
 // ------------------------------------------------------------------------------ forward
 static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* logits) {
     HeadArgs a;
-    a.h = h; a.T = c->T; a.D = c->D; a.E = c->E; a.K = c->K;
+    a.h = c->text ? c->hpool : h; a.T = c->text ? 1 : c->T; a.D = c->D; a.E = c->E; a.K = c->K;
     a.ln_g = c->postg; a.ln_b = c->postb; a.eps = c->c.ln_eps;
     a.WpT = c->wpT; a.Wp = c->wp; a.tfeat = c->tfeat; a.tfeatT = c->tfeatT; a.scale = c->scale;
     a.cls_mean = c->cls_mean; a.cls_rstd = c->cls_rstd; a.y = c->ycls; a.f = c->feat; a.logits = logits; a.feats_out = feats_out;
@@ -419,6 +488,7 @@ static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* l
 }
 
 static int lora_refresh(ttl_ctx* c, hipStream_t s) {
+    if (!c->lora_p) return 0;
     Prof p(c, 4, s);
     const size_t per = (size_t)c->r * c->D;
     for (int i = 0; i < c->nT; ++i) {
@@ -437,17 +507,24 @@ static int lora_refresh(ttl_ctx* c, hipStream_t s) {
 // inference on view 0 (rows 0..T-1 of that buffer).
 static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_layer, float* logits_out, float* feats_out,
                         void* stream) {
-    if (!c || (!x && from_layer == 0)) return fail(TTL_EINVAL, "null argument");
+    if (!c || (!x && from_layer == 0 && !c->text)) return fail(TTL_EINVAL, "null argument");
     if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
-    if (c->K < 1) return fail(TTL_ESTATE, "ttl_set_text_features has not been called");
-    if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
+    if (c->K < 1 && (logits_out || c->text || save))   // a features-only forward of the image tower needs no peer features
+        return fail(TTL_ESTATE, c->text ? "ttl_set_image_features has not been called" : "ttl_set_text_features has not been called");
+    if (!c->lora_p && save) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
+    if (c->text && n != c->n_prompts) return fail(TTL_ESTATE, "text forward over %d prompts, ttl_set_prompts gave %d", n, c->n_prompts);
+    const int causal = c->text;
     int rc = ttl_weights_ready(c);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H;
     if ((rc = lora_refresh(c, s))) return rc;
     float* h = c->h;
-    if (from_layer == 0) {
+    if (from_layer == 0 && c->text) {
+        Prof p(c, 3, s);
+        HIP_TRY(launch_text_embed(c->ids, c->tok, c->pos, c->h, M, T, D, s));   // no pre-LN in the text tower
+        c->stream_views = n;
+    } else if (from_layer == 0) {
         // patch embedding: im2col -> GEMM (+pos) ; CLS rows
         {
             Prof p(c, 3, s);
@@ -471,7 +548,8 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     }
     for (int i = from_layer; i < c->L; ++i) {
         Layer& l = c->layers[i];
-        const bool tr = l.trained;          // LoRA path active (B == 0 forever in the other layers, Q10)
+        const bool tr = l.trained && c->lora_p;   // LoRA path active (B == 0 forever in the other layers, Q10; no adapters
+                                                  // at all on the image tower when the text tower is the one being tuned)
         const bool sv = tr && save;
         op_t* x1 = tr ? l.x1ext : c->x1;
         const int ldx1 = tr ? c->ldx : D;
@@ -494,7 +572,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         }
         {
             Prof p(c, 1, s);
-            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s));
+            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s, causal));
         }
         float* h_mid = tr ? l.h_mid : h_in;
         {
@@ -525,9 +603,14 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     }
     {
         Prof p(c, 5, s);
+        if (c->text) HIP_TRY(launch_gather_rows_f32(h, D, c->pool, T, c->hpool, n, D, s));   // end-of-text rows -> [n, D]
         HeadArgs a = head_args(c, h, feats_out, c->logits);
         HIP_TRY(launch_head_fwd(a, n, s));
-        if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, c->logits, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (c->text) {   // the head produced [prompts, views]; the loss and the caller want [views, prompts]
+            HIP_TRY(launch_transpose_f32(c->logits, n, c->K, c->logits_nk, s));
+            if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, c->logits_nk, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else if (logits_out)
+            HIP_TRY(hipMemcpyAsync(logits_out, c->logits, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     c->saved = save != 0;
     c->saved_n = n;
@@ -535,7 +618,15 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
 }
 
 int ttl_vit_forward(ttl_ctx* c, const float* x, int n, int save, float* logits_out, float* feats_out, void* stream) {
+    if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_forward on a text-tower context (use ttl_text_forward)");
     return forward_impl(c, x, n, save, 0, logits_out, feats_out, stream);
+}
+
+int ttl_text_forward(ttl_ctx* c, int save, float* logits_out, float* feats_out, void* stream) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    if (!c->text) return fail(TTL_ESTATE, "ttl_text_forward needs a text-tower context");
+    if (c->n_prompts < 1) return fail(TTL_ESTATE, "ttl_set_prompts has not been called");
+    return forward_impl(c, nullptr, c->n_prompts, save, 0, logits_out, feats_out, stream);
 }
 
 int ttl_entropy_select_loss(const float* logits, int N, int K, int mode, double rho, float thresh, float margin, float reweight,
@@ -570,11 +661,13 @@ int ttl_tpt_select_loss(const float* logits, int N, int K, double rho, int reuse
 }
 
 // ------------------------------------------------------------------------------ backward
-int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
+static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) {
     if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");
-    if (!c->saved || c->saved_n != n) return fail(TTL_ESTATE, "no saved forward for %d views (call ttl_vit_forward with save_for_backward)", n);
+    if (!c->saved || c->saved_n != n) return fail(TTL_ESTATE, "no saved forward for %d sequences (run the forward with save_for_backward)", n);
     hipStream_t s = (hipStream_t)stream;
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H, r = c->r;
+    const int causal = c->text;
+    const int* pool = c->text ? c->pool : nullptr;
     int rc;
     float* dh = c->dh;      // gradient w.r.t. the residual stream at the current depth
     float* dh_alt = c->dh2;
@@ -592,10 +685,23 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
             // ---- top layer: the loss reads the CLS token only, so d/d h_out is non-zero on the n CLS
             // rows: MLP, LN2 and out_proj backward run on a compact [n, .] problem (row pitch T*D / T*F
             // picks the CLS rows of the saved activations) and attention backward is rank-1 per head.
+            // pooled rows of the saved activations: token 0 of every view sits at a fixed pitch (image tower);
+            // the end-of-text position differs per prompt, so the text tower gathers them into compact copies
+            const op_t* u_rows = l.u; int ld_u = T * F;
+            const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
+            const float *mu2 = l.mu2, *rs2 = l.rs2; int stat_pitch = T;
+            if (pool) {
+                Prof p(c, 3, s);
+                HIP_TRY(launch_gather_rows_op(l.u, F, pool, T, c->u_g, n, F, s));
+                HIP_TRY(launch_gather_rows_f32(l.h_mid, D, pool, T, c->hmid_g, n, D, s));
+                HIP_TRY(launch_gather_rows_f32(l.mu2, 1, pool, T, c->mu2_g, n, 1, s));
+                HIP_TRY(launch_gather_rows_f32(l.rs2, 1, pool, T, c->rs2_g, n, 1, s));
+                u_rows = c->u_g; ld_u = F; hmid_rows = c->hmid_g; hmid_pitch = D; mu2 = c->mu2_g; rs2 = c->rs2_g; stat_pitch = 1;
+            }
             {
                 GemmArgs a = {};
                 a.A = c->dcls16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = n; a.N = F; a.K = D;
-                a.C = c->dgc; a.ldc = F; a.aux = l.u; a.ldaux = T * F;
+                a.C = c->dgc; a.ldc = F; a.aux = u_rows; a.ldaux = ld_u;
                 if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
             }
             {
@@ -606,8 +712,8 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
             }
             {
                 Prof p(c, 3, s);
-                HIP_TRY(launch_layernorm_bwd(c->dxc, l.h_mid, l.mu2, l.rs2, l.ln2g, c->dcls, c->dhmc, c->dhmc16, n, D, s,
-                                             (long long)T * D, (long long)D, T, 0));
+                HIP_TRY(launch_layernorm_bwd(c->dxc, hmid_rows, mu2, rs2, l.ln2g, c->dcls, c->dhmc, c->dhmc16, n, D, s,
+                                             hmid_pitch, (long long)D, stat_pitch, 0));
             }
             {
                 GemmArgs a = {};
@@ -617,7 +723,8 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, D, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
+                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, D, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s,
+                                                 pool, causal));
             }
             dres_cls = c->dhmc;
         } else {
@@ -647,7 +754,7 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s));
+                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s, causal));
             }
             dres_cls = nullptr;
         }
@@ -670,13 +777,26 @@ int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream)
         {
             Prof p(c, 3, s);
             if (dres_cls)
-                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dres_cls, dh, c->dh16, M, D, s, 0, 0, 1, T));
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dres_cls, dh, c->dh16, M, D, s, 0, 0, 1, T, pool));
             else
                 HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s));
         }
         // dh now holds d/d h_in of layer i == d/d h_out of layer i-1
     }
     return 0;
+}
+
+int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
+    if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_backward_lora on a text-tower context (use ttl_text_backward_lora)");
+    return backward_impl(c, dlogits, n, stream);
+}
+
+int ttl_text_backward_lora(ttl_ctx* c, const float* dlogits, void* stream) {
+    if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");
+    if (!c->text) return fail(TTL_ESTATE, "ttl_text_backward_lora needs a text-tower context");
+    // the caller's gradient is [views, prompts]; the head backward walks prompts
+    HIP_TRY(launch_transpose_f32(dlogits, c->K, c->n_prompts, c->dlogits_kn, (hipStream_t)stream));
+    return backward_impl(c, c->dlogits_kn, c->n_prompts, stream);
 }
 
 int ttl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
@@ -695,6 +815,7 @@ int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, vo
 
 int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (!c || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
+    if (c->text) return fail(TTL_ESTATE, "ttl_episode on a text-tower context (use ttl_episode_text)");
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -709,7 +830,7 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf, c->dlogits,
                                         c->loss_scratch, s));
         }
-        if ((rc = ttl_vit_backward_lora(c, c->dlogits, a->n_views, stream))) return rc;
+        if ((rc = backward_impl(c, c->dlogits, a->n_views, stream))) return rc;
         {
             Prof p(c, 5, s);
             HIP_TRY(launch_adamw(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
@@ -720,6 +841,46 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     // adapted prediction on view 0 (ttl.py:350-352): layers below layer_lo are unchanged by the
     // update, so resume from the stream row block of view 0
     return forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
+}
+
+// --lora_encoder text (clip/custom_clip.py:672-678): image features of the views without grad on the image-tower
+// context `v` (no adapters bound), then the same update loop on the text-tower context `c`.
+int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* stream) {
+    if (!c || !v || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
+    if (!c->text || v->text) return fail(TTL_ESTATE, "ttl_episode_text(text_ctx, image_ctx, ...): wrong tower kinds");
+    if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called on the text context");
+    if (c->n_prompts < 1) return fail(TTL_ESTATE, "ttl_set_prompts has not been called");
+    if (a->n_views > c->c.max_classes) return fail(TTL_EINVAL, "n_views %d exceeds the text context's capacity %d", a->n_views, c->c.max_classes);
+    if (v->E != c->E) return fail(TTL_EINVAL, "embed dims differ (%d vs %d)", v->E, c->E);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
+    // image side: forward only; its own logits (against whatever peer features it holds) are not used
+    float* feats = v->head_te;   // [max_views, E] scratch of the image context
+    if ((rc = forward_impl(v, a->x, a->n_views, 0, 0, nullptr, feats, stream))) return rc;
+    if ((rc = set_peer_features(c, feats, a->n_views, 1, c->scale, s))) return rc;
+    const int N = a->n_views, K = c->n_prompts;
+    for (int u = 0; u < a->n_updates; ++u) {
+        if ((rc = forward_impl(c, nullptr, K, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr, stream)))
+            return rc;
+        {
+            Prof p(c, 5, s);
+            HIP_TRY(launch_entropy_loss(c->logits_nk, N, K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
+                                        (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf,
+                                        c->dlogits_nk, c->loss_scratch, s));
+            HIP_TRY(launch_transpose_f32(c->dlogits_nk, N, K, c->dlogits_kn, s));
+        }
+        if ((rc = backward_impl(c, c->dlogits_kn, K, stream))) return rc;
+        {
+            Prof p(c, 5, s);
+            HIP_TRY(launch_adamw(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                 a->weight_decay, u + 1, c->n_buf, s));
+        }
+    }
+    // adapted prediction on view 0: new text features (layers below layer_lo unchanged -> resume), row 0 of the logits
+    if ((rc = forward_impl(c, nullptr, K, 0, a->n_updates < 1 ? 0 : c->c.layer_lo, nullptr, nullptr, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(a->logits1_out, c->logits_nk, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------ kernel-level entry points
@@ -742,15 +903,15 @@ int ttl_cast_f32_operand(const float* src, void* dst, size_t n, void* stream) {
     return 0;
 }
 
-int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n, int T, int H, void* stream) {
-    HIP_TRY(launch_attention_fwd((const op_t*)qkv, 3 * H * 64, (op_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream));
+int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n, int T, int H, int causal, void* stream) {
+    HIP_TRY(launch_attention_fwd((const op_t*)qkv, 3 * H * 64, (op_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream, causal));
     return 0;
 }
 
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int ld_dqkv, int n, int T,
-                      int H, int need_dk, void* stream) {
+                      int H, int need_dk, int causal, void* stream) {
     HIP_TRY(launch_attention_bwd((const op_t*)qkv, 3 * H * 64, (const op_t*)out, (const op_t*)dout, H * 64, lse, (op_t*)dqkv,
-                                 ld_dqkv, n, T, H, need_dk, (hipStream_t)stream));
+                                 ld_dqkv, n, T, H, need_dk, (hipStream_t)stream, causal));
     return 0;
 }
 

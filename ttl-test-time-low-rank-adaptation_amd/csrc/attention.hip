@@ -1,4 +1,4 @@
-// Fused non-causal attention for head dim 64 (CLIP ViT-B/16: T=197, ViT-L/14: T=257).
+// Fused attention for head dim 64 (CLIP ViT-B/16: T=197, ViT-L/14: T=257; text tower: T=77, causal).
 //   forward : o = softmax(q k^T / 8) v, row logsumexp saved            (HF modeling_clip.py:259-277)
 //   backward: dq, dk, dv with P recomputed from the saved logsumexp     (autograd of the same)
 //
@@ -91,7 +91,7 @@ constexpr float SCALE = 0.125f;  // head_dim^-0.5, head_dim = 64
 // ------------------------------------------------------------------------------ forward
 template <int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
-                                                       int ldo, float* __restrict__ lse, int T, int H) {
+                                                       int ldo, float* __restrict__ lse, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
     char* sK = smem;
@@ -124,6 +124,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (32 * kt + acc_row(r, lane) >= T) a[r] = -INFINITY;
+            }
+            if (causal && kt >= qb) {   // keys after the query (the lane's query is qb*32 + lane%32)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kt + acc_row(r, lane) > qb * 32 + (lane & 31)) a[r] = -INFINITY;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, a[r]);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
 // per SIMD hide the LDS / exp latency that the 4-wave version (2 per SIMD) exposed.
 template <int NKT, int CH>
 __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
-                                                             int ldo, float* __restrict__ lse, int T, int H) {
+                                                             int ldo, float* __restrict__ lse, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32, NTHR = 64 * NKT;
     char* sK = smem;
@@ -212,6 +217,11 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (32 * kt + acc_row(r, lane) >= T) a[r] = -INFINITY;
+                }
+                if (causal && kt >= wave) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * kt + acc_row(r, lane) > q) a[r] = -INFINITY;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, a[r]);
@@ -264,7 +274,7 @@ template <int NKT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
                                                           const op_t* __restrict__ out, const op_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse,
-                                                          op_t* __restrict__ dqkv, int ldd, int T, int H) {
+                                                          op_t* __restrict__ dqkv, int ldd, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
     char* sK = smem;
@@ -307,7 +317,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = (32 * kt + acc_row(r, lane) < T) ? __expf(s[r] * SCALE - l) : 0.f;
+                const int key = 32 * kt + acc_row(r, lane);
+                float p = (key < T && !(causal && key > q)) ? __expf(s[r] * SCALE - l) : 0.f;
                 s[r] = p * (dp[r] - delta);  // dS^T
             }
 #pragma unroll
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
                                                            const op_t* __restrict__ out,
                                                            const op_t* __restrict__ dout, int ldo,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv,
-                                                           int ldd, int T, int H) {
+                                                           int ldd, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
     char* sQ = smem;
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int qi = 32 * qt + acc_row(r, lane);
-                float p = (qi < T) ? __expf(s[r] * SCALE - sLse[qi]) : 0.f;
+                float p = (qi < T && !(causal && key > qi)) ? __expf(s[r] * SCALE - sLse[qi]) : 0.f;
                 s[r] = p;
                 ds[r] = p * (dp[r] - sDelta[qi]);
             }
@@ -418,7 +429,7 @@ template <bool NEED_DK>
 __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restrict__ qkv, int ld, const op_t* __restrict__ out,
                                                            int ldo, const op_t* __restrict__ dout_cls,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv, int ldd,
-                                                           int T, int H) {
+                                                           int T, int H, const int* __restrict__ qpos, int causal) {
     // 8 lanes per key, lane c of the group owns head-dim chunk c (8 values = one 16-B access): every
     // load / store instruction touches whole 128-B rows
     __shared__ float sq[64], sdo[64], sred[32][64];
@@ -427,15 +438,16 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
     const op_t* base = qkv + (size_t)img * T * ld + head * 64;
+    const int qp = qpos ? qpos[img] : 0;   // the one query with a non-zero d(out): CLS, or end-of-text
     if (tid < 64) {
-        sq[tid] = op_to_f32(base[tid]);
+        sq[tid] = op_to_f32(base[(size_t)qp * ld + tid]);
         float d = op_to_f32(dout_cls[(size_t)img * D + head * 64 + tid]);
         sdo[tid] = d;
-        float prod = wave_sum(d * op_to_f32(out[(size_t)img * T * ldo + head * 64 + tid]));
+        float prod = wave_sum(d * op_to_f32(out[((size_t)img * T + qp) * ldo + head * 64 + tid]));
         if (tid == 0) sdelta = prod;
     }
     __syncthreads();
-    const float l0 = lse[((size_t)img * H + head) * T];
+    const float l0 = lse[((size_t)img * H + head) * T + qp];
     const float delta = sdelta;
     const int c = tid & 7, grp = tid >> 3;            // 32 key groups per pass
     float qc[8], dc[8], dq[8];
@@ -452,10 +464,11 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
         for (int e = 0; e < 8; ++e) { s = fmaf(qc[e], (float)kf[e], s); dp = fmaf(dc[e], (float)vf[e], dp); }
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); dp += __shfl_xor(dp, o, 64); }
-        const float p = __expf(s * SCALE - l0);
+        const bool live = ok && !(causal && j > qp);
+        const float p = live ? __expf(s * SCALE - l0) : 0.f;
         // the MFMA path rounds P and dS to the operand type before the second products; same points here
         const float pb = op_to_f32(f32_to_op(p));
-        const float ds = ok ? op_to_f32(f32_to_op(p * (dp - delta))) : 0.f;
+        const float ds = live ? op_to_f32(f32_to_op(p * (dp - delta))) : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq[e] = fmaf(ds, (float)kf[e], dq[e]);
         if (ok) {
@@ -468,10 +481,10 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
             }
             *(u32x4*)(o + 2 * D) = dv;
             if (NEED_DK) *(u32x4*)(o + D) = dk;
-            if (j > 0) *(u32x4*)o = u32x4{0u, 0u, 0u, 0u};
+            if (j != qp) *(u32x4*)o = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    // dq_0[8c+e] = sum over the 32 key groups
+    // dq_qp[8c+e] = sum over the 32 key groups
 #pragma unroll
     for (int e = 0; e < 8; ++e) sred[grp][8 * c + e] = dq[e];
     __syncthreads();
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
         float v = 0.f;
 #pragma unroll 8
         for (int g = 0; g < 32; ++g) v += sred[g][tid];
-        dqkv[(size_t)(img * T) * ldd + head * 64 + tid] = f32_to_op(v * SCALE);
+        dqkv[((size_t)img * T + qp) * ldd + head * 64 + tid] = f32_to_op(v * SCALE);
     }
 }
 
@@ -489,26 +502,26 @@ hipError_t set_smem(K kernel, int bytes) {
 }
 
 template <int NKT, int CH>
-hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
     static bool done = false;
     if (!done) { hipError_t e = set_smem(attn_fwd_w_kernel<NKT, CH>, SMEM); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((attn_fwd_w_kernel<NKT, CH>), dim3(n * H), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H);
+    hipLaunchKernelGGL((attn_fwd_w_kernel<NKT, CH>), dim3(n * H), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
 
 template <int NKT>
-hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
     static bool done = false;
     if (!done) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((attn_fwd_kernel<NKT>), dim3(n * H), dim3(256), SMEM, s, qkv, ld, out, ldo, lse, T, H);
+    hipLaunchKernelGGL((attn_fwd_kernel<NKT>), dim3(n * H), dim3(256), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
 
 template <int NKT>
 hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
-                 op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s) {
+                 op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s, int causal) {
     // one wave per 32-row block (NKT waves) for the ViT geometries, 4 waves otherwise
     constexpr int NW = 4;   // (one wave per block, NW = NKT, measured slower here: the dQ pass needs 256 VGPRs)
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
@@ -522,57 +535,57 @@ hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int
         done = true;
     }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, NW>), dim3(n * H), dim3(64 * NW), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
-                       ldd, T, H);
+                       ldd, T, H, causal);
     if (need_dk)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
-                           lse, dqkv, ldd, T, H);
+                           lse, dqkv, ldd, T, H, causal);
     else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
-                           lse, dqkv, ldd, T, H);
+                           lse, dqkv, ldd, T, H, causal);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
-                                hipStream_t s) {
+                                hipStream_t s, int causal) {
     int nkt = (T + 31) / 32;
-    if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-    if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-    if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+    if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+    if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     static int variant = -1;
     if (variant < 0) { const char* v = getenv("TTL_ATTN_VARIANT"); variant = v ? atoi(v) : 1; }
     if (variant >= 1) {
-        if (nkt == 7 && variant == 2) return fwd_w<7, 1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-        if (nkt == 7 && variant == 3) return fwd_w<7, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-        if (nkt == 7) return fwd_w<7, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-        if (nkt == 9) return fwd_w<9, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+        if (nkt == 7 && variant == 2) return fwd_w<7, 1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+        if (nkt == 7 && variant == 3) return fwd_w<7, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+        if (nkt == 7) return fwd_w<7, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+        if (nkt == 9) return fwd_w<9, 2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     }
-    if (nkt <= 7) return fwd_t<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
-    if (nkt <= 9) return fwd_t<9>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
+    if (nkt <= 7) return fwd_t<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+    if (nkt <= 9) return fwd_t<9>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
-                                hipStream_t s) {
+                                hipStream_t s, int causal) {
     int nkt = (T + 31) / 32;
-    if (nkt <= 1) return bwd_t<1>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
-    if (nkt <= 2) return bwd_t<2>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
-    if (nkt <= 4) return bwd_t<4>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
-    if (nkt <= 7) return bwd_t<7>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
-    if (nkt <= 9) return bwd_t<9>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s);
+    if (nkt <= 1) return bwd_t<1>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
+    if (nkt <= 2) return bwd_t<2>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
+    if (nkt <= 4) return bwd_t<4>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
+    if (nkt <= 7) return bwd_t<7>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
+    if (nkt <= 9) return bwd_t<9>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
-                                    hipStream_t s) {
+                                    hipStream_t s, const int* qpos, int causal) {
     if (need_dk)
         hipLaunchKernelGGL((attn_bwd_cls_kernel<true>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
-                           ld_dqkv, T, H);
+                           ld_dqkv, T, H, qpos, causal);
     else
         hipLaunchKernelGGL((attn_bwd_cls_kernel<false>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
-                           ld_dqkv, T, H);
+                           ld_dqkv, T, H, qpos, causal);
     return hipGetLastError();
 }

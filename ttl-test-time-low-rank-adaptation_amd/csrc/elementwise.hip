@@ -136,18 +136,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ o32, op_t* __restrict__ o16, int rows, int D,
-                                                     long long xs, long long os, int stat_stride, int dres_T) {
+                                                     long long xs, long long os, int stat_stride, int dres_T,
+                                                     const int* __restrict__ pool) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
     const int nch = D >> 2;
     const float mu = mean[(size_t)row * stat_stride], rs = rstd[(size_t)row * stat_stride];
-    // dres_T > 0: the residual gradient is non-zero only on rows that are multiples of dres_T
-    // (the CLS tokens) and is stored compactly as [rows / dres_T][D]
+    // dres_T > 0: the residual gradient is non-zero only on the pooled row of every sequence (token 0 =
+    // CLS for the image tower, pool[v] = end-of-text position for the text tower) and is stored
+    // compactly as [rows / dres_T][D]
     const float* dres_row = nullptr;
     if (dres) {
-        if (dres_T > 0) { if (row % dres_T == 0) dres_row = dres + (size_t)(row / dres_T) * D; }
-        else dres_row = dres + (size_t)row * os;
+        if (dres_T > 0) {
+            const int v = row / dres_T, t = row - v * dres_T;
+            if (t == (pool ? pool[v] : 0)) dres_row = dres + (size_t)v * D;
+        } else dres_row = dres + (size_t)row * os;
     }
     float4 dxh[LN_MAXC], xh[LN_MAXC];
     float s1 = 0.f, s2 = 0.f;
@@ -175,6 +179,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
             if (o16) *(u32x2*)(o16 + (size_t)row * os + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
         }
+    }
+}
+
+// text tower embedding (HF CLIPTextEmbeddings): h[p][t][:] = tok[ids[p][t]][:] + pos[t][:]
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                                         const float* __restrict__ pos, float* __restrict__ h, int rows, int T, int D) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 each
+    const int nch = D >> 2;
+    if (i >= (size_t)rows * nch) return;
+    const int row = (int)(i / nch), c = (int)(i - (size_t)row * nch);
+    const float4 a = *(const float4*)(tok + (size_t)ids[row] * D + 4 * c);
+    const float4 b = *(const float4*)(pos + (size_t)(row % T) * D + 4 * c);
+    *(float4*)(h + (size_t)row * D + 4 * c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// dst[v][0..cols) = src[(v*T + pool[v]) * ld + 0..cols)   (pooled rows of every sequence -> compact)
+template <typename Tp>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const Tp* __restrict__ src, long long ld, const int* __restrict__ pool,
+                                                          int T, Tp* __restrict__ dst, int n, int cols) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * cols) return;
+    const int v = (int)(i / cols), c = (int)(i - (size_t)v * cols);
+    dst[i] = src[((size_t)v * T + pool[v]) * ld + c];
+}
+
+// dst[c][r] = src[r][c]  (small fp32 matrices: logits between [views,prompts] and [prompts,views])
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * C) return;
+    const int c = (int)(i / R), r = (int)(i - (size_t)c * R);
+    dst[i] = src[(size_t)r * C + c];
+}
+
+// one block per row: dst[v][:] = src[v][:] / ||src[v]|| (or a plain copy), dstT[:][v] likewise
+__global__ __launch_bounds__(256) void unit_rows_kernel(const float* __restrict__ src, int n, int E, int normalize,
+                                                        float* __restrict__ dst, float* __restrict__ dstT) {
+    __shared__ float red[4];
+    const int v = blockIdx.x;
+    float nn = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) { float t = src[(size_t)v * E + e]; nn += t * t; }
+    nn = wave_sum(nn);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nn;
+    __syncthreads();
+    const float nrm = normalize ? sqrtf((red[0] + red[1]) + (red[2] + red[3])) : 1.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const float t = normalize ? src[(size_t)v * E + e] / nrm : src[(size_t)v * E + e];
+        dst[(size_t)v * E + e] = t;
+        dstT[(size_t)e * n + v] = t;
     }
 }
 
@@ -247,11 +299,41 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, op_t* out_bf16, int rows,
                                 int D, hipStream_t s, long long x_stride, long long o_stride, int stat_stride,
-                                int dres_T) {
+                                int dres_T, const int* pool) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
                        out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D,
-                       stat_stride, dres_T);
+                       stat_stride, dres_T, pool);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_embed(const int* ids, const float* tok, const float* pos, float* h, int rows, int T, int D, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    size_t n4 = (size_t)rows * (D / 4);
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ids, tok, pos, h, rows, T, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows_f32(const float* src, long long ld, const int* pool, int T, float* dst, int n, int cols, hipStream_t s) {
+    size_t tot = (size_t)n * cols;
+    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld, pool, T, dst, n, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows_op(const op_t* src, long long ld, const int* pool, int T, op_t* dst, int n, int cols, hipStream_t s) {
+    size_t tot = (size_t)n * cols;
+    hipLaunchKernelGGL((gather_rows_kernel<op_t>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld, pool, T, dst, n, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_f32(const float* src, int R, int C, float* dst, hipStream_t s) {
+    size_t tot = (size_t)R * C;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, R, C, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_unit_rows(const float* src, int n, int E, int normalize, float* dst, float* dstT, hipStream_t s) {
+    hipLaunchKernelGGL(unit_rows_kernel, dim3(n), dim3(256), 0, s, src, n, E, normalize, dst, dstT);
     return hipGetLastError();
 }
 

@@ -327,7 +327,7 @@ hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
                                     a.eps, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(head_proj_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.D * sizeof(float), s, a);
-    hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
+    if (a.K > 0) hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
     return hipGetLastError();
 }
 

@@ -55,23 +55,34 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, op_t* out_bf16,
                                 int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0,
-                                int stat_stride = 1, int dres_T = 0);
+                                int stat_stride = 1, int dres_T = 0, const int* pool = nullptr);
+// text tower: h[row][:] = tok[ids[row]][:] + pos[row % T][:]   (fp32, like HF CLIPTextEmbeddings)
+hipError_t launch_text_embed(const int* ids, const float* tok, const float* pos, float* h, int rows, int T, int D, hipStream_t s);
+// dst[v][0..cols) = src[(v*T + pool[v]) * ld + 0..cols): the pooled row of every sequence, compact
+hipError_t launch_gather_rows_f32(const float* src, long long ld, const int* pool, int T, float* dst, int n, int cols, hipStream_t s);
+hipError_t launch_gather_rows_op(const op_t* src, long long ld, const int* pool, int T, op_t* dst, int n, int cols, hipStream_t s);
+// dst [C,R] = src [R,C]^T (fp32)
+hipError_t launch_transpose_f32(const float* src, int R, int C, float* dst, hipStream_t s);
+// dst [n,E] = rows of src (divided by their L2 norm when normalize), dstT [E,n] the same transposed
+hipError_t launch_unit_rows(const float* src, int n, int E, int normalize, float* dst, float* dstT, hipStream_t s);
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // out[m][n] = (resid ? resid[m][n] : 0) + (bias ? bias[n] : 0) + sum_s part[s][m][n]   (fixed order: deterministic)
 hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr,
                                 const float* bias, float* out, int ldc, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
+// causal != 0: key j is visible to query i only for j <= i (text tower)
 hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T,
-                                int H, hipStream_t s);
+                                int H, hipStream_t s, int causal = 0);
 hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
-                                hipStream_t s);
-// Same gradients when d(out) is non-zero only for the CLS query of every view (the top layer):
-// dout_cls bf16 [n][H*64]; writes dense dq (zero rows for tokens > 0), dk, dv.
+                                hipStream_t s, int causal = 0);
+// Same gradients when d(out) is non-zero only for ONE query of every sequence (the top layer): token 0
+// (CLS) or, with qpos != null, token qpos[sequence] (end-of-text).  dout_cls bf16 [n][H*64]; writes dense
+// dq (zero rows for every other token), dk, dv.
 hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
-                                    hipStream_t s);
+                                    hipStream_t s, const int* qpos = nullptr, int causal = 0);
 
 // ---------------------------------------------------------------- head / loss / optimizer (head_loss.hip)
 struct HeadArgs {

@@ -208,6 +208,7 @@ hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, co
 #define SK(N_, K_) if (ncg == N_ && ks == K_ && D % 32 == 0) return skinny_launch<N_, K_>(X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M, s)
     SK(2, 24); SK(4, 24);      // ViT-B/16, r = 16 / 32
     SK(2, 32); SK(4, 32);      // ViT-L/14
+    SK(2, 16); SK(4, 16);      // text tower of ViT-B/16 (D = 512)
     SK(2, 4);  SK(4, 4);       // reduced test geometry (D = 128)
 #undef SK
     return hipErrorInvalidValue;

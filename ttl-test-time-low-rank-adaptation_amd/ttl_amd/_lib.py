@@ -23,11 +23,15 @@ class TtlError(RuntimeError):
     pass
 
 
+TTL_TOWER_IMAGE, TTL_TOWER_TEXT = 0, 1
+
+
 class ttl_config(C.Structure):
     _fields_ = [("image_size", C.c_int), ("patch_size", C.c_int), ("width", C.c_int), ("heads", C.c_int),
                 ("mlp", C.c_int), ("layers", C.c_int), ("embed", C.c_int), ("rank", C.c_int),
                 ("lora_alpha", C.c_float), ("layer_lo", C.c_int), ("layer_hi", C.c_int), ("ln_eps", C.c_float),
-                ("max_views", C.c_int), ("max_classes", C.c_int)]
+                ("max_views", C.c_int), ("max_classes", C.c_int), ("tower", C.c_int), ("context_length", C.c_int),
+                ("vocab_size", C.c_int)]
 
 
 class ttl_episode_args(C.Structure):
@@ -62,8 +66,14 @@ SIGNATURES = {
     "ttl_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ttl_layernorm_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "ttl_cast_f32_operand": (_I, [_P, _P, _Z, _P]),
-    "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "ttl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ttl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ttl_set_logit_scale": (_I, [_P, _F]),
+    "ttl_set_prompts": (_I, [_P, _P, _I, _P]),
+    "ttl_set_image_features": (_I, [_P, _P, _I, _I, _F, _P]),
+    "ttl_text_forward": (_I, [_P, _I, _P, _P, _P]),
+    "ttl_text_backward_lora": (_I, [_P, _P, _P]),
+    "ttl_episode_text": (_I, [_P, _P, C.POINTER(ttl_episode_args), _P]),
     "ttl_make_views_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "ttl_make_views": (_I, [_P, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _Z, _P]),
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),

@@ -51,6 +51,43 @@ class VitConfig:
         return VitConfig(**d)
 
 
+@dataclass(frozen=True)
+class TextConfig:
+    """Geometry of the CLIP text tower (``--lora_encoder text``, clip/custom_clip.py:602-607): same
+    pre-LN encoder layers as the image tower, causal attention over ``context_length`` tokens, pooled at
+    the end-of-text token.  Field names shared with VitConfig mean the same thing."""
+    name: str = "ViT-B/16-text"
+    context_length: int = 77
+    vocab_size: int = 49408
+    width: int = 512
+    heads: int = 8
+    mlp: int = 2048
+    layers: int = 12
+    embed: int = 512
+    ln_eps: float = 1e-5
+    rank: int = 16
+    lora_alpha: float = 32.0
+    layer_lo: int = 9
+    layer_hi: int = 11
+
+    @property
+    def tokens(self) -> int:
+        return self.context_length
+
+    @property
+    def head_dim(self) -> int:
+        return self.width // self.heads
+
+    @property
+    def scaling(self) -> float:
+        return self.lora_alpha / self.rank
+
+    def replace(self, **kw) -> "TextConfig":
+        d = asdict(self)
+        d.update(kw)
+        return TextConfig(**d)
+
+
 VIT_B16 = VitConfig()
 VIT_L14 = VitConfig(name="ViT-L/14", patch_size=14, width=1024, heads=16, mlp=4096,
                     layers=24, embed=768, layer_lo=21, layer_hi=23)
@@ -59,6 +96,11 @@ VIT_TINY = VitConfig(name="tiny", image_size=64, patch_size=16, width=128, heads
                      layers=4, embed=64, layer_lo=1, layer_hi=3)
 VIT_TINY197 = VIT_TINY.replace(name="tiny197", image_size=224)
 
+TEXT_B16 = TextConfig()
+TEXT_L14 = TextConfig(name="ViT-L/14-text", width=768, heads=12, mlp=3072, embed=768)
+TEXT_TINY = TextConfig(name="tiny-text", width=128, heads=2, mlp=512, layers=4, embed=64, layer_lo=1, layer_hi=3)
+TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-L/14": TEXT_L14, "tiny": TEXT_TINY, "tiny197": TEXT_TINY}
+
 ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197}
 
 
@@ -66,3 +108,10 @@ def get_config(arch: str) -> VitConfig:
     if arch not in ARCHS:
         raise ValueError(f"unsupported arch {arch!r}; known: {sorted(ARCHS)}")
     return ARCHS[arch]
+
+
+def get_text_config(arch: str) -> TextConfig:
+    """Text tower that pairs with image tower ``arch`` (openai/clip-vit-* checkpoints)."""
+    if arch not in TEXT_ARCHS:
+        raise ValueError(f"unsupported arch {arch!r}; known: {sorted(TEXT_ARCHS)}")
+    return TEXT_ARCHS[arch]

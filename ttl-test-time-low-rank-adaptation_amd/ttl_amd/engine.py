@@ -37,9 +37,7 @@ class TTLEngine:
                                 "(oracle/ is a test checker, not a fallback)")
         self.max_views, self.max_classes = int(max_views), int(max_classes)
         self.n_classes = 0
-        c = _lib.ttl_config(cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers,
-                            cfg.embed, cfg.rank, cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps,
-                            self.max_views, self.max_classes)
+        c = self._make_config(cfg)
         self._ccfg = c
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -49,6 +47,11 @@ class TTLEngine:
         self.grads = torch.zeros(self.n_lora, dtype=torch.float32, device=self.device)
         self._params = None
         self._keep = []
+
+    def _make_config(self, cfg):
+        return _lib.ttl_config(cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers,
+                               cfg.embed, cfg.rank, cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps,
+                               self.max_views, self.max_classes, _lib.TTL_TOWER_IMAGE, 0, 0)
 
     def _check(self, rc):
         _lib.check(rc, self.lib)
@@ -108,6 +111,15 @@ class TTLEngine:
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_vit_forward(self._h, _ptr(x), n, 1 if save else 0, _ptr(logits), _ptr(feats), _stream()))
         return (logits, feats) if want_features else logits
+
+    def features(self, x: torch.Tensor):
+        """Un-normalised image features [N,E] only (no peer features / adapters needed): the image side of
+        --lora_encoder text, clip/custom_clip.py:672-674."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        feats = torch.empty((x.shape[0], self.cfg.embed), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_vit_forward(self._h, _ptr(x), x.shape[0], 0, None, _ptr(feats), _stream()))
+        return feats
 
     def backward(self, dlogits: torch.Tensor):
         d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
@@ -197,6 +209,82 @@ class TTLEngine:
         self._check(self.lib.ttl_profile_read(self._h, ms, cnt, C.byref(fl)))
         return ({k: ms[i] for i, k in enumerate(_lib.PROFILE_CLASSES)},
                 {k: cnt[i] for i, k in enumerate(_lib.PROFILE_CLASSES)}, fl.value)
+
+
+class TextTowerEngine(TTLEngine):
+    """The text tower of ``--lora_encoder text`` (clip/custom_clip.py:602-607): a context with causal
+    attention over the prompt tokens whose q/v LoRA is the thing being tuned.  ``max_prompts`` bounds K,
+    ``max_views`` the number of image views whose features it scores."""
+
+    def __init__(self, cfg, max_prompts: int, max_views: int, device, precision: str = "bf16"):
+        super().__init__(cfg, max_prompts, max_views, device, precision)
+        self.n_prompts = 0
+        self.n_views = 0
+
+    def _make_config(self, cfg):
+        return _lib.ttl_config(0, 0, cfg.width, cfg.heads, cfg.mlp, cfg.layers, cfg.embed, cfg.rank, cfg.lora_alpha,
+                               cfg.layer_lo, cfg.layer_hi, cfg.ln_eps, self.max_views, self.max_classes,
+                               _lib.TTL_TOWER_TEXT, cfg.context_length, cfg.vocab_size)
+
+    def set_logit_scale(self, logit_scale_exp: float):
+        self._check(self.lib.ttl_set_logit_scale(self._h, float(logit_scale_exp)))
+        self._scale = float(logit_scale_exp)
+
+    def set_prompts(self, ids):
+        """ids: int [K, context_length] (prompt_learner.tokenized_prompts, clip/custom_clip.py:655)."""
+        t = torch.as_tensor(ids).to(dtype=torch.int32).contiguous().cpu()
+        assert t.dim() == 2 and t.shape[1] == self.cfg.context_length
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_set_prompts(self._h, C.c_void_p(t.data_ptr()), t.shape[0], _stream()))
+        self.n_prompts = int(t.shape[0])
+
+    def set_image_features(self, feats: torch.Tensor, normalize: bool = True):
+        f = feats.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_set_image_features(self._h, _ptr(f), f.shape[0], 1 if normalize else 0, self._scale, _stream()))
+        self.n_views = int(f.shape[0])
+
+    def set_text_features(self, *a, **k):
+        raise _lib.TtlError("a text-tower context scores image features: use set_image_features")
+
+    def forward(self, save: bool = False, want_features: bool = False):
+        """-> logits [n_views, n_prompts] (and un-normalised text features [n_prompts, E])."""
+        logits = torch.empty((self.n_views, self.n_prompts), dtype=torch.float32, device=self.device)
+        feats = torch.empty((self.n_prompts, self.cfg.embed), dtype=torch.float32, device=self.device) if want_features else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_text_forward(self._h, 1 if save else 0, _ptr(logits), _ptr(feats), _stream()))
+        return (logits, feats) if want_features else logits
+
+    def backward(self, dlogits: torch.Tensor):
+        d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
+        assert tuple(d.shape) == (self.n_views, self.n_prompts)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_text_backward_lora(self._h, _ptr(d), _stream()))
+        return self.grads
+
+    def episode(self, image_engine: TTLEngine, x, snapshot, m, v, *, n_updates=1, objective="deyo",
+                mode=_lib.TTL_SEL_LE_THRESH, rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999),
+                eps=1e-8, weight_decay=1e-2, want_logits0=False):
+        """Whole text-mode episode as one enqueue; ``image_engine`` is an adapter-less image-tower engine."""
+        import math
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        n = x.shape[0]
+        l1 = torch.empty((1, self.n_prompts), dtype=torch.float32, device=self.device)
+        l0 = torch.empty((n, self.n_prompts), dtype=torch.float32, device=self.device) if want_logits0 else None
+        a = _lib.ttl_episode_args()
+        a.x, a.n_views, a.n_updates = x.data_ptr(), n, int(n_updates)
+        a.objective = 0 if objective == "deyo" else 1
+        a.mode, a.rho = int(mode), float(rho)
+        a.thresh = math.log(1000.0) if thresh is None else thresh
+        a.margin, a.reweight = float(margin), float(reweight)
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, betas[0], betas[1], eps, weight_decay
+        a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.logits0_out = l0.data_ptr() if want_logits0 else None
+        a.logits1_out = l1.data_ptr()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_episode_text(self._h, image_engine._h, C.byref(a), _stream()))
+        self.n_views = n
+        return (l1, l0) if want_logits0 else l1
 
 
 def bf16_bits_to_f32(a: np.ndarray) -> np.ndarray:

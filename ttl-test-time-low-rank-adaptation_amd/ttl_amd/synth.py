@@ -70,16 +70,62 @@ def vision_weights(cfg: VitConfig, seed: int = 0) -> dict:
     return w
 
 
-def lora_init(cfg: VitConfig, seed: int = 0, targets=("q_proj", "v_proj")) -> dict:
+def text_weights(cfg, seed: int = 0) -> dict:
+    """fp32 state-dict (numpy) of the text tower + text_projection (HF names: ``text_model.embeddings.*``,
+    ``text_model.encoder.layers.{i}.*``, ``text_model.final_layer_norm``, ``text_projection``), same
+    scale choices as vision_weights.  ``cfg`` is a config.TextConfig."""
+    D, F, E, T, V = cfg.width, cfg.mlp, cfg.embed, cfg.context_length, cfg.vocab_size
+    w = {}
+    pre = "text_model."
+    w[pre + "embeddings.token_embedding.weight"] = _normal(seed, "t.tok", (V, D), 0.5)
+    w[pre + "embeddings.position_embedding.weight"] = _normal(seed, "t.pos", (T, D), 0.2)
+    w[pre + "final_layer_norm.weight"] = _normal(seed, "t.final.w", (D,), 0.1, 1.0)
+    w[pre + "final_layer_norm.bias"] = _normal(seed, "t.final.b", (D,), 0.05)
+    depth = float(cfg.layers)
+    for i in range(cfg.layers):
+        lp = f"{pre}encoder.layers.{i}."
+        for nm in ("layer_norm1", "layer_norm2"):
+            w[lp + nm + ".weight"] = _normal(seed, f"t.{i}.{nm}.w", (D,), 0.1, 1.0)
+            w[lp + nm + ".bias"] = _normal(seed, f"t.{i}.{nm}.b", (D,), 0.05)
+        qk_std = 1.2 / np.sqrt(D)
+        for nm, std in (("q_proj", qk_std), ("k_proj", qk_std), ("v_proj", 1.0 / np.sqrt(D)),
+                        ("out_proj", 1.0 / np.sqrt(D) / np.sqrt(depth))):
+            w[lp + f"self_attn.{nm}.weight"] = _normal(seed, f"t.{i}.{nm}.w", (D, D), std)
+            w[lp + f"self_attn.{nm}.bias"] = _normal(seed, f"t.{i}.{nm}.b", (D,), 0.02)
+        w[lp + "mlp.fc1.weight"] = _normal(seed, f"t.{i}.fc1.w", (F, D), 1.0 / np.sqrt(D))
+        w[lp + "mlp.fc1.bias"] = _normal(seed, f"t.{i}.fc1.b", (F,), 0.02)
+        w[lp + "mlp.fc2.weight"] = _normal(seed, f"t.{i}.fc2.w", (D, F), 1.0 / np.sqrt(F) / np.sqrt(depth))
+        w[lp + "mlp.fc2.bias"] = _normal(seed, f"t.{i}.fc2.b", (D,), 0.02)
+    w["text_projection.weight"] = _normal(seed, "t.proj", (E, D), 1.0 / np.sqrt(D))
+    return w
+
+
+def token_ids(n_prompts: int, cfg, seed: int = 0) -> np.ndarray:
+    """[K, context] int32 CLIP-style token rows: <sot>=V-2, 3..12 random word tokens, <eot>=V-1 (the
+    row maximum, which is how the pooled position is found: modeling_clip.py argmax(input_ids)), 0 pad."""
+    rng = _rng(seed, f"ids{n_prompts}")
+    T, V = cfg.context_length, cfg.vocab_size
+    ids = np.zeros((n_prompts, T), dtype=np.int32)
+    for k in range(n_prompts):
+        n = int(rng.integers(3, 13))
+        ids[k, 0] = V - 2
+        ids[k, 1:1 + n] = rng.integers(1, V - 2, n)
+        ids[k, 1 + n] = V - 1
+    return ids
+
+
+def lora_init(cfg, seed: int = 0, targets=("q_proj", "v_proj"), tower="vision_model") -> dict:
     """LoRA A (xavier_normal: std = sqrt(2/(D+r)), clip/custom_clip.py:152-153,184-187) and
-    B = 0 (peft default) for every layer, keyed like the reference's parameter names."""
+    B = 0 (peft default) for every layer, keyed like the reference's parameter names
+    (``tower`` = "vision_model" or "text_model")."""
     D, r = cfg.width, cfg.rank
     std = np.sqrt(2.0 / (D + r))
     out = {}
+    tag = "" if tower == "vision_model" else "t."
     for i in range(cfg.layers):
         for t in targets:
-            base = f"vision_model.encoder.layers.{i}.self_attn.{t}."
-            out[base + "lora_A.default.weight"] = _normal(seed, f"{i}.{t}.A", (r, D), std)
+            base = f"{tower}.encoder.layers.{i}.self_attn.{t}."
+            out[base + "lora_A.default.weight"] = _normal(seed, f"{tag}{i}.{t}.A", (r, D), std)
             out[base + "lora_B.default.weight"] = np.zeros((D, r), dtype=np.float32)
     return out
 
