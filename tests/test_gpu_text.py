@@ -1,5 +1,7 @@
 """-m gpu: --lora_encoder text through the C ABI — text tower forward, LoRA backward and the
 fused text-mode episode vs the bf16-emulating oracle (tight) and the reference-generated fixtures."""
+import math
+
 import numpy as np
 import pytest
 
@@ -145,3 +147,127 @@ def test_text_mode_errors_are_loud():
     with pytest.raises(_lib.TtlError):
         img.forward(torch.from_numpy(x).cuda(), save=True)  # saving for backward needs bound adapters
     img.close(); txt.close()
+
+
+# ------------------------------------------------------------------ host surface (drop-in) in text mode
+def build_model(name):
+    """ClipTestTimeTuning(lora_encoder='text') in the fixture's state + the optimizer of ttl.py:189-220."""
+    import copy
+    from ttl_amd.custom_clip import ClipTestTimeTuning
+    g, vcfg, tcfg, Wv, Wt, x, ids, lora0 = load_text_case(name)
+    K = ids.shape[0]
+    model = ClipTestTimeTuning(0, [f"c{i}" for i in range(K)], None, arch=vcfg.name, layer_range=[tcfg.layer_lo, tcfg.layer_hi],
+                               init_method="xavier", lora_encoder="text", rank=16, max_views=x.shape[0], max_classes=K,
+                               weight_seed=0)
+    layers = model.text_encoder.text_model.encoder.layers
+    with torch.no_grad():
+        for i, layer in enumerate(layers):
+            for pj in ("q_proj", "v_proj"):
+                key = f"text_model.encoder.layers.{i}.self_attn.{pj}.lora_A.default.weight"
+                getattr(layer.self_attn, pj).lora_A.default.weight.copy_(torch.from_numpy(lora0[key]))
+        model.LoRA_AB.init_weights = []
+        for layer in layers:
+            sa = layer.self_attn
+            model.LoRA_AB.init_weights.append(tuple(t.detach().clone() for t in (
+                sa.q_proj.lora_A.default.weight, sa.q_proj.lora_B.default.weight,
+                sa.v_proj.lora_A.default.weight, sa.v_proj.lora_B.default.weight)))
+    model.prompt_learner.tokenized_prompts = torch.from_numpy(ids.astype(np.int64))     # the fixture's prompts
+    model._text_dirty = True
+    # ttl.py:143-163 with lora_enc = 'text_encoder' / :189-220 over model.text_encoder.text_model.encoder.layers
+    for n, p in model.named_parameters():
+        p.requires_grad_("text_encoder" in n and ("lora_A" in n or "lora_B" in n)
+                         and any(f"layers.{i}." in n for i in range(tcfg.layer_lo, tcfg.layer_hi + 1)))
+    groups = []
+    for i, layer in enumerate(layers):
+        if tcfg.layer_lo <= i <= tcfg.layer_hi:
+            groups += [{"params": layer.self_attn.q_proj.lora_A.parameters()}, {"params": layer.self_attn.q_proj.lora_B.parameters()},
+                       {"params": layer.self_attn.v_proj.lora_A.parameters()}, {"params": layer.self_attn.v_proj.lora_B.parameters()}]
+    opt = torch.optim.AdamW(groups, lr=5e-3)
+    return g, tcfg, model, opt, copy.deepcopy(opt.state_dict()), torch.from_numpy(x).cuda()
+
+
+def text_args(**over):
+    import argparse
+    a = argparse.Namespace(lr=5e-3, selection_p=0.1, tta_steps=1, cocoop=False, lora_encoder="text", deyo_selection=True,
+                           deyo_margin=0.5, deyo_margin_e0=0.4, filter_ent=0, filter_plpd=0, reweight_ent=1, reweight_plpd=0)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_reference_shaped_loop_text_mode(name):
+    """The per-image sequence of ttl.py:338-352 on this build's surface with --lora_encoder text."""
+    from ttl_amd.ttl import test_time_tuning
+    g, tcfg, model, opt, opt_state, x = build_model(name)
+    kw = episode_kwargs(g)
+    args = text_args(filter_ent=1 if kw["mode"] == "topk" else 0, tta_steps=int(round(kw["n_updates"] ** 0.5)))
+    names = [n for n, _ in model.named_parameters()]
+    assert any(n.startswith("text_encoder.text_model.encoder.layers.1.self_attn.q_proj.lora_A") for n in names)
+    assert not any("image_encoder" in n and "lora" in n for n in names)      # no adapters on the image tower in this mode
+    model.eval()
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    with torch.no_grad():
+        z0 = model(x)
+    assert max_rel(z0.cpu().numpy(), g["logits0"]) < 3e-2
+    test_time_tuning(model, x, opt, None, args)
+    with torch.no_grad():
+        out = model(x[:1])
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 5e-2
+    assert int(out.argmax()) == int(g["top5"][0, 0])
+    # text features accessor of the reference surface
+    t = model.get_text_features()
+    assert tuple(t.shape) == (g["ids"].shape[0], tcfg.embed) and torch.allclose(t.norm(dim=-1), torch.ones_like(t[:, 0]), atol=1e-5)
+    assert max_rel(t.cpu().numpy(), g["text_features_after"]) < 5e-2
+
+
+def test_autograd_formulation_text_mode():
+    """The reference's own step (torch loss on model(x), loss.backward(), optimizer.step()) through the autograd hook."""
+    g, tcfg, model, opt, opt_state, x = build_model("tiny_text_deyo")
+    model.eval()
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    out = model(x)
+    ent = -(out.softmax(1) * out.log_softmax(1)).sum(1)
+    idx = torch.where(ent <= math.log(1000))[0]
+    e = ent[idx]
+    coeff = 1 / torch.exp(e.clone().detach() - 0.4)
+    loss = e.mul(coeff).mean(0)
+    opt.zero_grad()
+    loss.backward()
+    for n, p in model.named_parameters():
+        key = "grad/" + n.replace("text_encoder.", "")
+        if p.requires_grad and key in g.files and np.abs(g[key]).max() > 0:
+            assert max_rel(p.grad.cpu().numpy(), g[key]) < 4e-2, n
+    opt.step()
+    with torch.no_grad():
+        o1 = model(x[:1])
+    assert int(o1.argmax()) == int(g["top5"][0, 0])
+
+
+def test_eval_loop_text_mode():
+    """ttl_amd.eval.test_time_adapt_eval with lora_encoder='text' (fused text episodes, 2 in flight) == per-image surface."""
+    from ttl_amd.eval import test_time_adapt_eval, SyntheticViews
+    from ttl_amd.ttl import test_time_tuning
+    from ttl_amd.driver import topk_hits
+    from ttl_amd.config import VIT_TINY
+    g, tcfg, model, opt, opt_state, x = build_model("tiny_text_deyo")
+    args = text_args()
+    data = SyntheticViews(VIT_TINY, 4, 8, 10, seed=3)
+    hits = torch.zeros(2, dtype=torch.int64)
+    for views, label in data:
+        with torch.no_grad():
+            model.LoRA_reset()
+        opt.load_state_dict(opt_state)
+        test_time_tuning(model, views.cuda(), opt, None, args)
+        with torch.no_grad():
+            out = model(views[:1].cuda())
+        h1, h5 = topk_hits(out.cpu(), torch.tensor([label]))
+        hits += torch.stack([h1, h5])
+    with torch.no_grad():
+        model.LoRA_reset()
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=2)
+    assert abs(top1 - 100.0 * hits[0].item() / 4) < 1e-9 and abs(top5 - 100.0 * hits[1].item() / 4) < 1e-9

@@ -68,7 +68,26 @@ def test_init_method_errors_like_reference():
     with pytest.raises(ValueError):
         ClipTestTimeTuning("cpu", ["a"], None, arch="tiny", layer_range=[1, 3], init_method="bogus", lora_encoder="image")
     with pytest.raises(NotImplementedError):
-        ClipTestTimeTuning("cpu", ["a"], None, arch="tiny", layer_range=[1, 3], lora_encoder="text")
+        ClipTestTimeTuning("cpu", ["a"], None, arch="tiny", layer_range=[1, 3], lora_encoder="prompt")
+
+
+def test_text_mode_module_tree_matches_the_reference_names():
+    """--lora_encoder text (ttl.py:143-147,190-192): adapters hang off text_encoder.text_model.encoder.layers,
+    the image tower carries none; reset restores the snapshot; running it on the CPU is an error, not a fallback."""
+    m = ClipTestTimeTuning("cpu", ["a", "b"], None, arch="tiny", layer_range=[1, 3], init_method="xavier", lora_encoder="text")
+    names = [n for n, _ in m.named_parameters()]
+    assert "text_encoder.text_model.encoder.layers.2.self_attn.v_proj.lora_B.default.weight" in names
+    assert not any("image_encoder" in n for n in names)
+    ps = m.trainable_lora_parameters()
+    assert len(ps) == 12 and ps[0].shape == (16, 128) and ps[1].shape == (128, 16)
+    a0 = ps[0].detach().clone()
+    with torch.no_grad():
+        ps[0].add_(1.0)
+    m.LoRA_reset()
+    assert torch.equal(ps[0], a0)
+    from ttl_amd._lib import TtlError
+    with pytest.raises(TtlError):
+        m(torch.zeros(2, 3, 64, 64))
 
 
 def test_get_ttl_alias_and_rank_forwarding():

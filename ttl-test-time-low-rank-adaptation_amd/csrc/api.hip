@@ -509,7 +509,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
                         void* stream) {
     if (!c || (!x && from_layer == 0 && !c->text)) return fail(TTL_EINVAL, "null argument");
     if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
-    if (c->K < 1 && (logits_out || c->text || save))   // a features-only forward of the image tower needs no peer features
+    if (c->K < 1 && (logits_out || save))   // a features-only forward needs no peer features
         return fail(TTL_ESTATE, c->text ? "ttl_set_image_features has not been called" : "ttl_set_text_features has not been called");
     if (!c->lora_p && save) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     if (c->text && n != c->n_prompts) return fail(TTL_ESTATE, "text forward over %d prompts, ttl_set_prompts gave %d", n, c->n_prompts);
@@ -606,7 +606,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         if (c->text) HIP_TRY(launch_gather_rows_f32(h, D, c->pool, T, c->hpool, n, D, s));   // end-of-text rows -> [n, D]
         HeadArgs a = head_args(c, h, feats_out, c->logits);
         HIP_TRY(launch_head_fwd(a, n, s));
-        if (c->text) {   // the head produced [prompts, views]; the loss and the caller want [views, prompts]
+        if (c->text && c->K > 0) {   // the head produced [prompts, views]; the loss and the caller want [views, prompts]
             HIP_TRY(launch_transpose_f32(c->logits, n, c->K, c->logits_nk, s));
             if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, c->logits_nk, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
         } else if (logits_out)

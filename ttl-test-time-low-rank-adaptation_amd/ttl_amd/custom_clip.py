@@ -1,4 +1,5 @@
-"""Host-side mirror of the reference's LoRA-CLIP wrapper, for the image-LoRA path only.
+"""Host-side mirror of the reference's LoRA-CLIP wrapper: lora_encoder = 'image' (the north-star path)
+and 'text' (the text tower then runs on the HIP path too).
 
 Same names, argument meaning and error behaviour as clip/custom_clip.py of the reference:
 ``ClipTestTimeTuning`` (:570-703), ``LoRA_AB`` (:139-217), ``VisionEncoder`` (:62-71),
@@ -17,7 +18,10 @@ What differs by design (MI355X-native):
     lora_encoder == 'image'; the reference recomputes them in every forward — SURVEY Q12);
   * adapters of layers outside ``layer_range`` have B == 0 forever in the reference (Q10) and are
     therefore numerically absent here; their Parameters still exist for name-compatibility.
-The text tower stays PyTorch (transformers.CLIPModel), as BASELINE.json's north_star asks.
+In image mode the text tower stays PyTorch (transformers.CLIPModel), as BASELINE.json's north_star asks.
+In text mode (clip/custom_clip.py:602-607,672-678) the adapters sit on
+``text_encoder.text_model.encoder.layers.{i}.self_attn.{q_proj,v_proj}``, the image tower carries none
+and only supplies features, and both towers run in libttl_hip contexts.
 """
 import math
 import os
@@ -28,8 +32,8 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from . import synth
-from .config import get_config
-from .engine import TTLEngine
+from .config import get_config, get_text_config
+from .engine import TTLEngine, TextTowerEngine
 
 CLIP_WEIGHTS_ENV = "TTL_CLIP_WEIGHTS"   # local HF checkpoint dir of openai/clip-vit-base-patch16 (optional)
 
@@ -92,12 +96,67 @@ class _VitLogitsFn(torch.autograd.Function):
         return (None, None, None, *outs)
 
 
+class _TextModeEngine:
+    """TTLEngine's call surface for the host loops when lora_encoder == 'text': ``forward(x)`` = image
+    features of the views on the adapter-less image context (no grad, clip/custom_clip.py:672-674) ->
+    text tower with grad (:677-678) -> logits [N,K]; ``backward`` goes through the text LoRA only."""
+
+    def __init__(self, img: TTLEngine, txt: TextTowerEngine):
+        self.img, self.txt = img, txt
+        self.device, self.max_views, self.precision = txt.device, img.max_views, txt.precision
+        self.lib = txt.lib
+
+    grads = property(lambda self: self.txt.grads)
+    n_classes = property(lambda self: self.txt.n_prompts)
+
+    def forward(self, x, save=False, want_features=False):
+        self.txt.set_image_features(self.img.features(x), normalize=True)
+        return self.txt.forward(save=save, want_features=want_features)
+
+    def backward(self, dlogits):
+        return self.txt.backward(dlogits)
+
+    def bind_lora(self, flat):
+        self.txt.bind_lora(flat)
+
+    def episode(self, x, snapshot, m, v, **kw):
+        return self.txt.episode(self.img, x, snapshot, m, v, **kw)
+
+    def entropy_select_loss(self, *a, **k):
+        return self.txt.entropy_select_loss(*a, **k)
+
+    def tpt_select_loss(self, *a, **k):
+        return self.txt.tpt_select_loss(*a, **k)
+
+    def adamw_step(self, *a, **k):
+        return self.txt.adamw_step(*a, **k)
+
+    def lora_reset(self, *a, **k):
+        return self.txt.lora_reset(*a, **k)
+
+    def close(self):
+        self.img.close()
+        self.txt.close()
+
+
+def build_text_mode_engine(vcfg, tcfg, vision_state, text_state, prompts, logit_scale_exp, device, max_views, max_prompts,
+                           precision="bf16"):
+    """Image context (no adapters) + text-tower context with prompts and logit scale set; LoRA still unbound."""
+    img = TTLEngine(vcfg, max_views, 1, device, precision)
+    img.load_weights(vision_state)
+    txt = TextTowerEngine(tcfg, max_prompts, max_views, device, precision)
+    txt.load_weights(text_state)
+    txt.set_logit_scale(logit_scale_exp)
+    txt.set_prompts(prompts)
+    return _TextModeEngine(img, txt)
+
+
 class VisionEncoder(nn.Module):
     """clip/custom_clip.py:62-71.  ``forward(image)`` returns image features [N,E]."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, adapters=True):
         super().__init__()
-        self.vision_model = _VisionModel(cfg)
+        self.vision_model = _VisionModel(cfg) if adapters else nn.Module()
         self.dtype = torch.float32
         self._owner = None
 
@@ -118,6 +177,21 @@ class PromptEncoder(nn.Module):
         out = self.text_model(input_ids=prompts)
         pooled = out.pooler_output if hasattr(out, "pooler_output") else out[1]
         return self.text_projection(pooled)
+
+
+class TextEncoderHIP(nn.Module):
+    """The text tower when it is the tuned one (lora_encoder == 'text'): holds the adapter parameters under the
+    reference's names (``text_model.encoder.layers.{i}.self_attn.{q,v}_proj.lora_{A,B}.default.weight``);
+    ``forward(prompts)`` returns text features [K,E] from the HIP context (no grad)."""
+
+    def __init__(self, tcfg):
+        super().__init__()
+        self.text_model = _VisionModel(tcfg)     # same encoder.layers[i].self_attn.{q,v}_proj adapter tree
+        self.dtype = torch.float32
+        self._owner = None
+
+    def forward(self, prompts=None):
+        return self._owner.text_features_raw()
 
 
 class LoRA_AB:
@@ -143,10 +217,15 @@ class LoRA_AB:
             fn = None
         else:
             raise ValueError(f"Unsupported init_method: {self.init_method}")
-        if self.lora_encoder != 'image':
-            raise NotImplementedError("only lora_encoder='image' is implemented on the HIP path (SURVEY.md §8f-4)")
-        for layer in self.model.vision_model.encoder.layers:
+        for layer in self._layers():
             self.initialize_layer_weights(layer, fn)
+
+    def _layers(self):
+        if self.lora_encoder == 'image':
+            return self.model.vision_model.encoder.layers
+        if self.lora_encoder == 'text':
+            return self.model.text_model.encoder.layers
+        raise NotImplementedError(f"lora_encoder={self.lora_encoder!r}: prompt tuning is out of scope (SURVEY.md §8)")
 
     def initialize_layer_weights(self, layer, fn):
         aq = layer.self_attn.q_proj.lora_A.default.weight
@@ -161,7 +240,7 @@ class LoRA_AB:
         self.init_weights.append((aq.detach().clone(), bq.detach().clone(), av.detach().clone(), bv.detach().clone()))
 
     def reset(self):
-        layers = self.model.vision_model.encoder.layers
+        layers = self._layers()
         for i, layer in enumerate(layers):
             if i in range(self.layer_range[0], self.layer_range[1] + 1):
                 aq, bq, av, bv = self.init_weights[i]
@@ -220,6 +299,8 @@ def _build_clip(cfg, weights_dir, seed):
         vis = {k: v for k, v in sd.items() if k.startswith("vision_model.") or k == "visual_projection.weight"}
         vis = {k: v for k, v in vis.items() if "position_ids" not in k}
         vis["logit_scale"] = sd["logit_scale"]
+        model._ttl_text_state = {k: v for k, v in sd.items()
+                                 if (k.startswith("text_model.") or k == "text_projection.weight") and "position_ids" not in k}
         return model, vis, tokenizer
     tw = 64 if cfg.width <= 128 else 512
     conf = CLIPConfig(
@@ -243,15 +324,14 @@ def _build_clip(cfg, weights_dir, seed):
 
 # ------------------------------------------------------------------------------- the model
 class ClipTestTimeTuning(nn.Module):
-    """clip/custom_clip.py:570-703 for lora_encoder='image'."""
+    """clip/custom_clip.py:570-703 for lora_encoder in ('image', 'text')."""
 
     def __init__(self, device, classnames, batch_size, criterion='cosine', arch="ViT-B/16", n_ctx=16, ctx_init=None,
                  ctx_position='end', learned_cls=False, layer_range=[9, 11], init_method=None, lora_encoder='text',
                  rank=16, max_views=64, max_classes=1000, weight_seed=0, precision="bf16"):
         super().__init__()
-        if lora_encoder != 'image':
-            raise NotImplementedError(f"lora_encoder={lora_encoder!r}: only the image-LoRA path is built "
-                                      "(text-LoRA / prompt tuning are SURVEY.md §8f-4 / out of scope)")
+        if lora_encoder not in ('image', 'text'):
+            raise NotImplementedError(f"lora_encoder={lora_encoder!r}: prompt tuning is out of scope (SURVEY.md §8)")
         self.device = torch.device(f"cuda:{device}" if isinstance(device, int) else device)
         self.lora_encoder = lora_encoder
         cfg = get_config(arch)
@@ -263,12 +343,20 @@ class ClipTestTimeTuning(nn.Module):
         self.max_classes = max(int(max_classes), len(classnames))
         clip_model, vis_state, tokenizer = _build_clip(cfg, os.environ.get(CLIP_WEIGHTS_ENV), weight_seed)
         self._vision_state = vis_state
-        self.image_encoder = VisionEncoder(cfg)
+        self.image_encoder = VisionEncoder(cfg, adapters=(lora_encoder == 'image'))
         object.__setattr__(self.image_encoder, "_owner", self)
-        self.text_encoder = PromptEncoder(clip_model)
-        for p in self.text_encoder.parameters():
-            p.requires_grad_(False)
-        self.LoRA_AB = LoRA_AB(self.image_encoder, layer_range=layer_range, init_method=init_method, lora_encoder=lora_encoder)
+        if lora_encoder == 'image':
+            self.tcfg = None
+            self.text_encoder = PromptEncoder(clip_model)
+            for p in self.text_encoder.parameters():
+                p.requires_grad_(False)
+            self.LoRA_AB = LoRA_AB(self.image_encoder, layer_range=layer_range, init_method=init_method, lora_encoder=lora_encoder)
+        else:
+            self.tcfg = get_text_config(arch).replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1])
+            self._text_state = getattr(clip_model, "_ttl_text_state", None) or synth.text_weights(self.tcfg, weight_seed)
+            self.text_encoder = TextEncoderHIP(self.tcfg)
+            object.__setattr__(self.text_encoder, "_owner", self)
+            self.LoRA_AB = LoRA_AB(self.text_encoder, layer_range=layer_range, init_method=init_method, lora_encoder=lora_encoder)
         ls = vis_state["logit_scale"]
         self.logit_scale = torch.as_tensor(np.asarray(ls) if not isinstance(ls, torch.Tensor) else ls.detach().cpu()).float()
         self.prompt_learner = PromptLearner(tokenizer, classnames, ctx_init)
@@ -284,8 +372,9 @@ class ClipTestTimeTuning(nn.Module):
     def trainable_lora_parameters(self):
         """The 4*nT tensors in the order of ttl.py:195-213."""
         out = []
+        tower = self.image_encoder.vision_model if self.lora_encoder == 'image' else self.text_encoder.text_model
         for i in range(self.layer_range[0], self.layer_range[1] + 1):
-            sa = self.image_encoder.vision_model.encoder.layers[i].self_attn
+            sa = tower.encoder.layers[i].self_attn
             out += [sa.q_proj.lora_A.default.weight, sa.q_proj.lora_B.default.weight,
                     sa.v_proj.lora_A.default.weight, sa.v_proj.lora_B.default.weight]
         return out
@@ -299,10 +388,16 @@ class ClipTestTimeTuning(nn.Module):
         if self.engine is None or self.engine.device != dev:
             if self.engine is not None:
                 self.engine.close()
-            self.engine = TTLEngine(self.cfg, self.max_views, self.max_classes, dev, self.precision)
-            self.engine.load_weights(self._vision_state)
+            if self.lora_encoder == 'text':
+                self.engine = build_text_mode_engine(self.cfg, self.tcfg, self._vision_state, self._text_state,
+                                                     self.prompt_learner.tokenized_prompts, float(self.logit_scale.exp()), dev,
+                                                     self.max_views, self.max_classes, self.precision)
+                self._text_dirty = False
+            else:
+                self.engine = TTLEngine(self.cfg, self.max_views, self.max_classes, dev, self.precision)
+                self.engine.load_weights(self._vision_state)
+                self._text_dirty = True
             self._flat = None
-            self._text_dirty = True
         # (re)alias the trained parameters onto one flat buffer the fused kernels can walk
         off, ok = 0, self._flat is not None
         if ok:
@@ -320,7 +415,10 @@ class ClipTestTimeTuning(nn.Module):
             self._opt_m = torch.zeros_like(flat)
             self._opt_v = torch.zeros_like(flat)
             self._snap = None
-        if self._text_dirty:
+        if self._text_dirty and self.lora_encoder == 'text':
+            self.engine.txt.set_prompts(self.prompt_learner.tokenized_prompts)
+            self._text_dirty = False
+        elif self._text_dirty:
             with torch.no_grad():
                 self.text_features = self.get_text_features()
             self.engine.set_text_features(self.text_features, float(self.logit_scale.exp()))
@@ -331,6 +429,8 @@ class ClipTestTimeTuning(nn.Module):
         """Second context for forwards that must not disturb the activations saved for a pending backward
         (the PLPD forward of deyo.py:135 sits between model(x) and loss.backward()).  Shares the LoRA
         parameter buffer, so it always sees the current adapter weights."""
+        if self.lora_encoder == 'text':
+            raise NotImplementedError("--filter_plpd with --lora_encoder text is not built")
         self._ensure_engine()
         aux = getattr(self, "_aux", None)
         if aux is None or aux.device != self.engine.device or aux.n_classes != self.engine.n_classes \
@@ -380,7 +480,19 @@ class ClipTestTimeTuning(nn.Module):
                 self.engine = None
         self._text_dirty = True
 
+    def text_features_raw(self):
+        """lora_encoder == 'text': un-normalised text features [K,E] with the current adapters (HIP, no grad)."""
+        eng = self._ensure_engine()
+        feats = torch.empty((eng.txt.n_prompts, self.tcfg.embed), dtype=torch.float32, device=eng.device)
+        from .engine import _ptr, _stream
+        with torch.cuda.device(eng.device):
+            eng.txt._check(eng.txt.lib.ttl_text_forward(eng.txt._h, 0, None, _ptr(feats), _stream()))
+        return feats
+
     def get_text_features(self):
+        if self.lora_encoder == 'text':
+            t = self.text_features_raw()
+            return t / t.norm(dim=-1, keepdim=True)
         dev = next(self.text_encoder.parameters()).device
         t = self.text_encoder(self.prompt_learner.tokenized_prompts.to(dev))
         t = t / t.norm(dim=-1, keepdim=True)
@@ -388,6 +500,8 @@ class ClipTestTimeTuning(nn.Module):
 
     def image_features_of(self, image):
         eng = self._ensure_engine()
+        if self.lora_encoder == 'text':
+            return eng.img.features(image)
         _, f = eng.forward(image, save=False, want_features=True)
         return f
 

@@ -81,32 +81,43 @@ class EpisodePipeline:
     """
 
     def __init__(self, cfg, weights, lora_names, lora_init, text_features, logit_scale_exp, device, n_streams=2,
-                 max_views=64, precision="bf16"):
+                 max_views=64, precision="bf16", engine_factory=None, n_classes=None):
+        """``engine_factory`` (optional): callable returning a ready engine (weights loaded, peer features /
+        prompts set, LoRA unbound) with ``bind_lora`` / ``episode`` / ``close`` — used for
+        ``--lora_encoder text`` (custom_clip.build_text_mode_engine); default: an image-tower TTLEngine."""
         from .engine import TTLEngine
         self.slots = []
         dev = torch.device(device)
         for _ in range(max(1, int(n_streams))):
-            eng = TTLEngine(cfg, max_views, text_features.shape[0], dev, precision)
-            eng.load_weights(weights)
-            eng.set_text_features(text_features, logit_scale_exp)
+            if engine_factory is not None:
+                eng = engine_factory()
+            else:
+                eng = TTLEngine(cfg, max_views, text_features.shape[0], dev, precision)
+                eng.load_weights(weights)
+                eng.set_text_features(text_features, logit_scale_exp)
             flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in lora_names]).to(dev).contiguous()
             eng.bind_lora(flat)
             self.slots.append(dict(eng=eng, flat=flat, snap=flat.clone(), m=torch.zeros_like(flat), v=torch.zeros_like(flat),
                                    stream=torch.cuda.Stream(device=dev),
                                    acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
         self._next = 0
-        self.max_classes = int(text_features.shape[0])
+        self.max_classes = int(n_classes if n_classes is not None else text_features.shape[0])
         self.lora_names = list(lora_names)
         torch.cuda.synchronize(dev)
 
-    def rebind(self, lora_init, text_features, logit_scale_exp):
+    def rebind(self, lora_init, text_features=None, logit_scale_exp=None, prompts=None):
         """New dataset on the same frozen weights (the reference loops over set_ids, ttl.py:262-298):
-        fresh class-text features, LoRA snapshot and accuracy accumulators; contexts and arenas stay."""
-        if int(text_features.shape[0]) > self.max_classes:
+        fresh class-text features (image mode) or tokenized prompts (text mode), LoRA snapshot and
+        accuracy accumulators; contexts and arenas stay."""
+        n_new = int(prompts.shape[0] if prompts is not None else text_features.shape[0])
+        if n_new > self.max_classes:
             raise ValueError("more classes than the pipeline was built for")
         self.synchronize()
         for sl in self.slots:
-            sl["eng"].set_text_features(text_features, logit_scale_exp)
+            if prompts is not None:
+                sl["eng"].txt.set_prompts(prompts)
+            else:
+                sl["eng"].set_text_features(text_features, logit_scale_exp)
             flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in self.lora_names]).to(sl["flat"].device)
             sl["flat"].copy_(flat)
             sl["snap"].copy_(flat)

@@ -54,14 +54,26 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
     key = (int(n_streams), model.precision, eng.max_views)
     cache = model.__dict__.setdefault("_episode_pipelines", {})
     pipe = cache.get(key)
-    if pipe is not None and pipe.max_classes >= model.text_features.shape[0]:
-        pipe.rebind(init, model.text_features, float(model.logit_scale.exp()))
+    scale = float(model.logit_scale.exp())
+    text_mode = model.lora_encoder == 'text'
+    prompts = model.prompt_learner.tokenized_prompts
+    n_cls = int(prompts.shape[0]) if text_mode else int(model.text_features.shape[0])
+    if pipe is not None and pipe.max_classes >= n_cls:
+        if text_mode:
+            pipe.rebind(init, prompts=prompts)
+        else:
+            pipe.rebind(init, model.text_features, scale)
     else:
         if pipe is not None:
             pipe.close()
-        pipe = cache[key] = EpisodePipeline(model.cfg, model._vision_state, names, init, model.text_features,
-                                            float(model.logit_scale.exp()), eng.device, n_streams=n_streams,
-                                            max_views=eng.max_views, precision=model.precision)
+        factory = None
+        if text_mode:    # clip/custom_clip.py:602-607: adapters on the text tower, image tower forward-only
+            from .custom_clip import build_text_mode_engine
+            factory = lambda: build_text_mode_engine(model.cfg, model.tcfg, model._vision_state, model._text_state, prompts,
+                                                     scale, eng.device, eng.max_views, n_cls, model.precision)
+        pipe = cache[key] = EpisodePipeline(model.cfg, model._vision_state, names, init, model.text_features, scale,
+                                            eng.device, n_streams=n_streams, max_views=eng.max_views,
+                                            precision=model.precision, engine_factory=factory, n_classes=n_cls)
     dev = eng.device
     for i, (images, target) in enumerate(val_loader):
         if i % world != rank:
@@ -145,8 +157,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
+    ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
     a = ap.parse_args()
-    a.lora_encoder = "image"
     rank, local, world = dist_env()
     torch.cuda.set_device(local)
     if world > 1:
@@ -155,7 +167,7 @@ def main():
     from .custom_clip import ClipTestTimeTuning
     cfg = get_config(a.arch)
     model = ClipTestTimeTuning(local, [f"class {i}" for i in range(a.classes)], None, arch=a.arch,
-                               layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier", lora_encoder="image",
+                               layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier", lora_encoder=a.lora_encoder,
                                rank=a.rank, max_views=a.views, max_classes=a.classes, precision=a.precision)
     opt = torch.optim.AdamW([{"params": [p]} for p in model.trainable_lora_parameters()], lr=a.lr)
     aug = None
