@@ -225,6 +225,9 @@ int ttl_debug_copy(ttl_ctx* ctx, const char* name, int layer, void* host_dst, si
 int ttl_profile_enable(ttl_ctx* ctx, int on);
 int ttl_profile_read(ttl_ctx* ctx, double ms[TTL_NCLASS], long long launches[TTL_NCLASS],
                      double* gemm_flops);
+/* Algorithmic bytes (operands + outputs + fused epilogue inputs, each once) of the GEMM launches covered by the
+ * last ttl_profile_read: the denominator the measured HBM traffic of those launches is compared with. */
+int ttl_profile_gemm_bytes(ttl_ctx* ctx, double* bytes);
 
 #ifdef __cplusplus
 }

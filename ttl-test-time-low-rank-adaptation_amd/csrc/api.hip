@@ -107,7 +107,7 @@ struct ttl_ctx {
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
     bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
-    bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0;
+    bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_bytes = 0, gemm_bytes_last = 0;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
 
@@ -187,7 +187,15 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.padded = 1;   // every arena buffer has Mmax = round_up(N*T, 320) rows
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
-    if (c->prof) c->gemm_flops += 2.0 * a.M * a.N * a.K;
+    if (c->prof) {
+        c->gemm_flops += 2.0 * a.M * a.N * a.K;
+        // algorithmic bytes of the launch: both operands once, every output once, the fused epilogue inputs once
+        const double mn = (double)a.M * a.N;
+        const bool f32out = (epi == EPI_F32 || epi == EPI_RESID_F32 || epi == EPI_PATCH);
+        c->gemm_bytes += 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + mn * (f32out ? 4 : 2) +
+                         (epi == EPI_RESID_F32 ? 4 * mn : 0) + (epi == EPI_GELU_BWD ? 2 * mn : 0) +
+                         (epi == EPI_GELU && a.C2 ? 2 * mn : 0);
+    }
     HIP_TRY(launch_gemm(epi, a, s));
     return 0;
 }
@@ -887,6 +895,9 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
 int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
     GemmArgs a = {};
     a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    static int padded = -1;   // TTL_GEMM_PADDED=1: the caller's C has round_up(M,320) rows -> the unguarded product kernel (bench tools)
+    if (padded < 0) { const char* v = getenv("TTL_GEMM_PADDED"); padded = v ? atoi(v) : 0; }
+    a.padded = padded;
     hipError_t e = launch_gemm(EPI_F32, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));
     return 0;
@@ -987,6 +998,14 @@ int ttl_profile_read(ttl_ctx* c, double ms[TTL_NCLASS], long long launches[TTL_N
     }
     if (gemm_flops) *gemm_flops = c->gemm_flops;
     c->gemm_flops = 0;
+    c->gemm_bytes_last = c->gemm_bytes;
+    c->gemm_bytes = 0;
+    return 0;
+}
+
+int ttl_profile_gemm_bytes(ttl_ctx* c, double* bytes) {
+    if (!c || !bytes) return fail(TTL_EINVAL, "null argument");
+    *bytes = c->gemm_bytes_last;
     return 0;
 }
 

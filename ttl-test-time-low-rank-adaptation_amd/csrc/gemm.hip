@@ -21,6 +21,13 @@ namespace {
 
 constexpr int BK = 64;
 
+// Diagnostic ablations of the main loop (tools/gemm_ablate.sh builds libttl_hip_diagN.so; results are WRONG on
+// purpose, only the timing is read): 1 = no DMA in the steady loop, 2 = no MFMA, 3 = no LDS fragment reads,
+// 4 = no barrier.  The product build has TTL_GEMM_DIAG == 0 and none of this exists in it.
+#ifndef TTL_GEMM_DIAG
+#define TTL_GEMM_DIAG 0
+#endif
+
 // compile-time unrolled scheduling hints: NP x { MFMA x MPER, (first NP0 rounds) DS_READ x DPER, VMEM x 1 }
 template <int I, int NP, int NP0, int MPER, int DPER>
 struct SchedLoop {
@@ -35,6 +42,22 @@ template <int NP, int NP0, int MPER, int DPER>
 struct SchedLoop<NP, NP, NP0, MPER, DPER> {
     static __device__ __forceinline__ void run() {}
 };
+
+// Output stores.  Measured (rocprofv3 --pmc FETCH_SIZE): the 58-155 MB of output a launch writes evict the
+// weight slice / activation panels from the 4 MiB L2s, e.g. fc1 fetches 118 MB where 24 MB are algorithmic;
+// non-temporal stores cut that to 64 MB but the GEMM is not faster (the re-reads hit the Infinity Cache) and
+// the CONSUMER kernels lose their Infinity-Cache hits (attention forward +11 %, episode +3.7 %): plain stores stay.
+#ifndef TTL_GEMM_NT_STORE
+#define TTL_GEMM_NT_STORE 0
+#endif
+template <typename V>
+__device__ __forceinline__ void st_out(V* p, V v) {
+#if TTL_GEMM_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 // ---- epilogue shared by both kernels: accumulator register r of sub-tile (mt, nt) is row
 // 16*mt + 4*lg + r, column 4*li + nt of the wave's 64-column slab: per (mt, r) a lane owns 4
@@ -66,10 +89,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     float4 t = *(const float4*)(a.resid + (size_t)m * a.ldr + n0);
                     v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
-                *(float4*)((float*)a.C + orow * a.ldc + n0) = make_float4(v0, v1, v2, v3);
+                st_out((f32x4*)((float*)a.C + orow * a.ldc + n0), f32x4{v0, v1, v2, v3});
             } else {
                 if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) *(u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0) = u32x2{pack_op2(v0, v1), pack_op2(v2, v3)};
+                    if (a.C2) st_out((u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
                 if constexpr (EPI == EPI_GELU_BWD) {
@@ -77,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
                     v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
                 }
-                *(u32x2*)((op_t*)a.C + (size_t)m * a.ldc + n0) = u32x2{pack_op2(v0, v1), pack_op2(v2, v3)};
+                st_out((u32x2*)((op_t*)a.C + (size_t)m * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
             }
         }
     }
@@ -108,10 +131,28 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     const int li = lane & 15, lg = lane >> 4;
 
     const int ntn = a.N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int row0 = (bid / ntn) * BM;
-    const int col0 = (bid % ntn) * BN;
     const int M = a.M;
+    int row0, col0;
+    if (a.xc > 0) {
+        // 2-D XCD partition (blocks b and b+8 share an XCD): the 8 XCDs form an (8/xc) x xc grid over
+        // (row tiles) x (column tiles), so an XCD's slice of the weight matrix, N/xc x K, stays in its 4 MiB
+        // L2 for the whole launch while the activation panels stream through it once per XCD column.
+        // With a 1-D order every XCD walks ALL of B once per row tile: at N*K*2 B > 4 MiB (fc1 / fc2 of
+        // ViT-B) that is an LRU-thrashing cyclic sweep served from the Infinity Cache.
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xr_n = 8 / a.xc, xr = x / a.xc, xcol = x - xr * a.xc;
+        const int ntm = (M + BM - 1) / BM;
+        const int r0 = xr * ntm / xr_n, r1 = (xr + 1) * ntm / xr_n;
+        const int cols = ntn / a.xc;
+        if (j >= (r1 - r0) * cols) return;   // uneven row split: the spare blocks of this XCD have no tile
+        const int jr = j / cols;
+        row0 = (r0 + jr) * BM;
+        col0 = (xcol * cols + (j - jr * cols)) * BN;
+    } else {
+        const int bid = xcd_remap(blockIdx.x, gridDim.x);
+        row0 = (bid / ntn) * BM;
+        col0 = (bid % ntn) * BN;
+    }
     // split-K (small-M fp32 partials): slice blockIdx.y covers K/splits and writes its own [M][ldc] slab
     const int nk = a.K / BK / a.splits;
     const size_t koff = (size_t)blockIdx.y * nk * BK;
@@ -164,6 +205,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
     constexpr int NP = NA + NB;            // DMA pieces per thread per K-tile
     constexpr int NP0 = (NP + 1) / 2;      // issued under the first 32-deep half, the rest under the second
     auto stage_piece = [&](int i, int kt, char* base) {
+        if (TTL_GEMM_DIAG == 1) return;
         if (i < NA)
             __builtin_amdgcn_global_load_lds(GLB_PTR(abase + (size_t)kt * (BK * sizeof(op_t)) + aoff[i]),
                                              LDS_PTR(base + (i * NTHR + wave * 64) * 16), 16, 0, 0);
@@ -172,6 +214,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
                                              LDS_PTR(base + A_BYTES + ((i - NA) * NTHR + wave * 64) * 16), 16, 0, 0);
     };
     auto load_frags = [&](const char* base, int s, opx8 (&xf)[MT], opx8 (&wf)[4]) {
+        if (TTL_GEMM_DIAG == 3) base = smem;   // loop-invariant address: hoisted out of the K loop by the compiler
         const int cA = ((4 * s + lg) ^ swA) << 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const opx8*)(base + offA[mt] + cA);
@@ -179,6 +222,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const opx8*)(base + offW[nt] + cA);
     };
     auto mma = [&](const opx8 (&xf)[MT], const opx8 (&wf)[4]) {
+        if (TTL_GEMM_DIAG == 2) {   // keep the LDS reads alive without the matrix pipe
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(xf[mt]));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(wf[nt]));
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -200,7 +250,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         // steady state: tile kt is consumed while tile kt+1's DMA is issued BETWEEN the MFMAs (the
         // matrix pipe never waits behind a burst of DMA issue); the last tile is peeled (no prefetch)
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
+            if (TTL_GEMM_DIAG != 4) __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done with the other stage
             const char* base = smem + (kt & 1) * STAGE;
             char* nxt = smem + ((kt + 1) & 1) * STAGE;
             opx8 xf0[MT], wf0[4], xf1[MT], wf1[4];
@@ -266,7 +316,21 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     }
     if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>), dim3(ntm * ntn, a.splits), dim3(64 * WMW * WNW), SMEM, s, a);
+    GemmArgs b = a;
+    b.xc = 0;
+    int nblk = ntm * ntn;
+    static int xcd2d = -1;
+    if (xcd2d < 0) { const char* v = getenv("TTL_GEMM_XCD2D"); xcd2d = v ? atoi(v) : 2; }   // 0 = 1-D order; n = slice limit n*1.5 MiB (+1 % in situ)
+    if (xcd2d && a.M >= 1024 && a.splits == 1 && ntm >= 8) {
+        // columns of the XCD grid: halve the weight slice until it sits comfortably in a 4 MiB L2
+        const size_t limit = (size_t)xcd2d * 1536 * 1024;
+        int xc = 1;
+        while (xc < 8 && (size_t)a.N * a.K * sizeof(op_t) / xc > limit && ntn % (2 * xc) == 0) xc *= 2;
+        const int xr_n = 8 / xc;
+        b.xc = xc;
+        nblk = 8 * ((ntm + xr_n - 1) / xr_n) * (ntn / xc);
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>), dim3(nblk, a.splits), dim3(64 * WMW * WNW), SMEM, s, b);
     return hipGetLastError();
 }
 
@@ -278,6 +342,12 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 //   double-buffered fragments, 2-3 blocks/CU ..................... 4.37-4.48 ms (twice the barriers per K)
 //   256x128x64, 8 waves in two groups one barrier apart (one loads
 //   fragments + issues DMA while the other issues MFMAs), 3 stages  +5% on the N >= 2304 shapes, +15% overall
+//   256x256x64 / 256x128x64 (2- and 3-stage), 8 waves, 1 block/CU  0.91 / 0.83 / 0.80 of the 160x128 rate on the
+//   QKV shape, worse on N = 768: 150-600 blocks quantise badly on 256 CUs and nothing hides a block's prologue
+// Ablations of the 160x128 loop on M=12800,N=2304,K=768 (tools/gemm_ablate.py): product 55.6 us; without the
+// DMA 38.0 us; without the MFMAs 43.9 us (= 14.5 TB/s of L2->LDS staging, the guide's L2-resident LDS-gather
+// rate is 17-19 TB/s); without the LDS fragment reads 52.5 us; without the barrier 52.4 us.  The kernel is
+// bound by L2->LDS staging at this tile's 71 FLOP per staged byte, not by LDS reads, barriers or MFMA issue.
 // M = 12608 gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 /
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's

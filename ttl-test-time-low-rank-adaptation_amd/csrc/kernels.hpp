@@ -27,6 +27,7 @@ struct GemmArgs {
     float* ws; size_t ws_bytes;   // optional split-K workspace (small-M fp32-output calls)
     int splits;                   // internal: K slices of this launch (blockIdx.y)
     int padded;                   // all C/resid/aux/C2 buffers have rows up to round_up(M, 320): unguarded epilogue allowed
+    int xc;                       // internal: columns of the 2-D XCD grid (0 = 1-D tile order)
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 

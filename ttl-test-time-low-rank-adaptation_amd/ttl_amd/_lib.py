@@ -79,6 +79,7 @@ SIGNATURES = {
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),
     "ttl_profile_enable": (_I, [_P, _I]),
     "ttl_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "ttl_profile_gemm_bytes": (_I, [_P, C.POINTER(C.c_double)]),
 }
 
 

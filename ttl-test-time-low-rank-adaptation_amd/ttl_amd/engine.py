@@ -207,6 +207,9 @@ class TTLEngine:
         cnt = (C.c_longlong * _lib.TTL_NCLASS)()
         fl = C.c_double()
         self._check(self.lib.ttl_profile_read(self._h, ms, cnt, C.byref(fl)))
+        by = C.c_double()
+        self._check(self.lib.ttl_profile_gemm_bytes(self._h, C.byref(by)))
+        self.last_gemm_bytes = by.value
         return ({k: ms[i] for i, k in enumerate(_lib.PROFILE_CLASSES)},
                 {k: cnt[i] for i, k in enumerate(_lib.PROFILE_CLASSES)}, fl.value)
 
