@@ -211,6 +211,12 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
             const int kt = c0 + j;
             if (kt < NKT) {
                 f32x16 a = {};
+                if (causal && kt > wave) {   // every key of this tile comes after every query of the wave: nothing to compute
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = -INFINITY;
+                    st[j] = a;
+                    continue;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) a = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], a, 0, 0, 0);
                 if (32 * kt + 32 > T) {
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-            if (c0 + j < NKT) {
+            if (c0 + j < NKT && !(causal && c0 + j > wave)) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     opx8 pf = acc_frag(st[j], s);
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
         f32x16 dq[2] = {};
 #pragma unroll 1
         for (int kt = 0; kt < NKT; ++kt) {
+            if (causal && kt > qb) break;   // keys after every query of this block
             f32x16 s = {}, dp = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
         }
         f32x16 dv[2] = {}, dk[2] = {};
 #pragma unroll 1
-        for (int qt = 0; qt < NKT; ++qt) {
+        for (int qt = (causal ? kb : 0); qt < NKT; ++qt) {   // causal: queries before this key block never see it
             f32x16 s = {}, dp = {};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -552,6 +559,7 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
+    if (nkt == 3) return fwd_w<3, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);   // text tower: T = 77
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     static int variant = -1;
     if (variant < 0) { const char* v = getenv("TTL_ATTN_VARIANT"); variant = v ? atoi(v) : 1; }
