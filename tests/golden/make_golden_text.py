@@ -32,6 +32,7 @@ CASES = {
     "tiny_text_deyo": ("tiny", 8, 10, {}),
     "tiny_text_topk": ("tiny", 64, 10, {"filter_ent": 1}),
     "tiny_text_steps2": ("tiny", 8, 10, {"tta_steps": 2}),
+    "tiny_text_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
     "b16_text_n8_k10": ("ViT-B/16", 8, 10, {}),
     "b16_text_n64_k200": ("ViT-B/16", 64, 200, {}),
 }
@@ -88,14 +89,19 @@ def run_case(case):
     hook.remove()
     z0 = rec["logits"][0]
     Hs = deyo.softmax_entropy(z0)
-    if args.filter_ent:
-        idx = torch.argsort(Hs, descending=False)[:int(Hs.size()[0] * args.selection_p)]
+    if not args.deyo_selection:                      # TPT objective on the text LoRA (ttl.py:87-108)
+        sel, idx = ttl.select_confident_samples(z0, args.selection_p)
+        coeff = torch.zeros(0)
+        loss = ttl.avg_entropy(sel.float())
     else:
-        idx = torch.where(Hs <= math.log(1000))[0]
-    e = Hs[idx]
-    coeff = args.reweight_ent * (1 / torch.exp(e.clone().detach() - args.deyo_margin_e0))
-    loss = e.mul(coeff).mean(0)
-    n_updates = args.tta_steps ** 2
+        if args.filter_ent:
+            idx = torch.argsort(Hs, descending=False)[:int(Hs.size()[0] * args.selection_p)]
+        else:
+            idx = torch.where(Hs <= math.log(1000))[0]
+        e = Hs[idx]
+        coeff = args.reweight_ent * (1 / torch.exp(e.clone().detach() - args.deyo_margin_e0))
+        loss = e.mul(coeff).mean(0)
+    n_updates = args.tta_steps ** 2 if args.deyo_selection else args.tta_steps
     assert len(rec["logits"]) == n_updates + 1
     with torch.no_grad():
         fimg = model.image_encoder(x)
@@ -104,7 +110,8 @@ def run_case(case):
     out = dict(arch=cfg.name, mode_encoder="text", rank=16, n_views=N, n_classes=K, weight_seed=0, view_seed=7, ids_seed=3,
                ids=ids.numpy().astype(np.int32),
                weights_sha256=synth.checksum(synth.vision_weights(cfg, 0)),
-               objective="deyo", mode="topk" if args.filter_ent else "le_thresh", rho=args.selection_p,
+               objective="deyo" if args.deyo_selection else "tpt",
+               mode="topk" if (args.filter_ent or not args.deyo_selection) else "le_thresh", rho=args.selection_p,
                margin=args.deyo_margin_e0, n_updates=n_updates, lr=args.lr,
                image_features=fimg.numpy(), text_features_after=model.text_features.detach().numpy(),
                logits0=z0.numpy(), H=Hs.numpy(), idx=idx.numpy().astype(np.int64), coeff=coeff.numpy(),

@@ -13,6 +13,7 @@ from helpers import load_text_case, episode_kwargs, max_rel, check_lora_step
 pytestmark = pytest.mark.gpu
 
 TINY = ["tiny_text_deyo", "tiny_text_topk", "tiny_text_steps2"]
+TINY_ALL = TINY + ["tiny_text_tpt"]
 
 
 def make(vcfg, tcfg, Wv, Wt, lora0, n_views, n_prompts, precision="bf16"):
@@ -75,7 +76,7 @@ def test_text_forward_and_backward(name):
     img.close(); txt.close()
 
 
-@pytest.mark.parametrize("name", TINY + ["b16_text_n8_k10", "b16_text_n64_k200"])
+@pytest.mark.parametrize("name", TINY_ALL + ["b16_text_n8_k10", "b16_text_n64_k200"])
 def test_text_episode(name):
     g, vcfg, tcfg, Wv, Wt, x, ids, lora0 = load_text_case(name)
     kw = episode_kwargs(g)
@@ -84,8 +85,8 @@ def test_text_episode(name):
     txt.set_prompts(ids)
     snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
     mode = 1 if kw["mode"] == "topk" else 0
-    l1, l0 = txt.episode(img, torch.from_numpy(x).cuda(), snap, m, v, n_updates=kw["n_updates"], mode=mode, rho=kw["rho"],
-                         margin=kw["margin"], lr=kw["lr"], want_logits0=True)
+    l1, l0 = txt.episode(img, torch.from_numpy(x).cuda(), snap, m, v, n_updates=kw["n_updates"], objective=kw["objective"],
+                         mode=mode, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"], want_logits0=True)
     torch.cuda.synchronize()
     l0, l1 = l0.cpu().numpy(), l1.cpu().numpy()
     # selection set of the first update: bit-exact vs the reference
@@ -195,13 +196,15 @@ def text_args(**over):
     return a
 
 
-@pytest.mark.parametrize("name", TINY)
+@pytest.mark.parametrize("name", TINY_ALL)
 def test_reference_shaped_loop_text_mode(name):
     """The per-image sequence of ttl.py:338-352 on this build's surface with --lora_encoder text."""
     from ttl_amd.ttl import test_time_tuning
     g, tcfg, model, opt, opt_state, x = build_model(name)
     kw = episode_kwargs(g)
-    args = text_args(filter_ent=1 if kw["mode"] == "topk" else 0, tta_steps=int(round(kw["n_updates"] ** 0.5)))
+    deyo = kw["objective"] == "deyo"
+    args = text_args(filter_ent=1 if (kw["mode"] == "topk" and deyo) else 0, deyo_selection=deyo,
+                     tta_steps=int(round(kw["n_updates"] ** 0.5)) if deyo else kw["n_updates"])
     names = [n for n, _ in model.named_parameters()]
     assert any(n.startswith("text_encoder.text_model.encoder.layers.1.self_attn.q_proj.lora_A") for n in names)
     assert not any("image_encoder" in n and "lora" in n for n in names)      # no adapters on the image tower in this mode

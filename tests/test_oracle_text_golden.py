@@ -6,7 +6,7 @@ import pytest
 from oracle import ttl_oracle as O
 from helpers import load_text_case, episode_kwargs, max_rel, check_lora_step
 
-CASES = ["tiny_text_deyo", "tiny_text_topk", "tiny_text_steps2"]
+CASES = ["tiny_text_deyo", "tiny_text_topk", "tiny_text_steps2", "tiny_text_tpt"]
 
 
 @pytest.mark.parametrize("name", CASES)
