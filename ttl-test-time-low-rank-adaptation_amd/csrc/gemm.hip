@@ -262,10 +262,26 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
 #pragma unroll
             for (int i = NP0; i < NP; ++i) stage_piece(i, kt + 1, nxt);
             mma(xf1, wf1);
+            // Main-loop order, measured IN SITU (tools/gemm_sched_ab.sh + quick_bench.py, GEMM ms per episode):
+            //   0 (used)  DMA pieces spread between the MFMAs ........ 3.52
+            //   1         fragments, the DMA as one burst, MFMAs ..... 3.57
+            //   2         the compiler's own order ................... 3.70
+            // A back-to-back microbenchmark of one shape (inputs and outputs resident in L2 / Infinity Cache,
+            // tools/gemm_ablate.py) ranks them the other way round (1 is 4-16 % ahead there): judge in situ.
+#ifndef TTL_GEMM_SCHED
+#define TTL_GEMM_SCHED 0
+#endif
+            if constexpr (TTL_GEMM_SCHED == 1) {          // all fragments, the DMA as one burst, all MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + 4), 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * 4, 0);
+            } else if constexpr (TTL_GEMM_SCHED == 2) {   // the compiler's own order
+            } else {
             // pin the interleave: fragments of the first half, then {MFMAs, one DMA piece, a few reads}
             __builtin_amdgcn_sched_group_barrier(0x100, MT + 4, 0);
             SchedLoop<0, NP, NP0, (2 * MT * 4) / NP, (MT + 4 + NP0 - 1) / NP0>::run();
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * 4 - NP * ((2 * MT * 4) / NP), 0);
+            }
         }
         {
             __syncthreads();

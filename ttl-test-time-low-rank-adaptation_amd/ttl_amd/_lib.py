@@ -11,6 +11,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libttl_hip.so")            # bf16 operands (default; BASELINE north_star)
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libttl_hip_fp16.so")}   # same ABI, operand dtype differs
+if os.environ.get("TTL_HIP_LIB_BF16"):     # A/B timing of experimental builds (tools/): another bf16 build of the same ABI
+    LIB_PATHS["bf16"] = os.environ["TTL_HIP_LIB_BF16"]
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ttl_hip.h"))
 
 TTL_SEL_LE_THRESH = 0
