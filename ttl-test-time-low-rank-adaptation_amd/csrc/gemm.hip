@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         gemm_epilogue<EPI, MT, GUARD>(e, acc, row0 + wm * WM, col0 + wn * 64 + 4 * li, lg, M);
 }
 
+
 template <int BM, int WMW, int WNW, int EPI, bool GUARD = true, int STAGES = 2>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BN = 64 * WNW;
@@ -364,6 +365,10 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 // DMA 38.0 us; without the MFMAs 43.9 us (= 14.5 TB/s of L2->LDS staging, the guide's L2-resident LDS-gather
 // rate is 17-19 TB/s); without the LDS fragment reads 52.5 us; without the barrier 52.4 us.  The kernel is
 // bound by L2->LDS staging at this tile's 71 FLOP per staged byte, not by LDS reads, barriers or MFMA issue.
+//   A through a 3-stage LDS ring + B straight from L2 into registers in MFMA operand layout (four waves side by
+//   side, 160 x 32 each; two K-tiles in flight per block instead of one; bit-identical results): 4.32 ms vs 3.47
+//   in situ.  A register-destination B load touches 16 lines x 64 B per instruction (half lines, twice the
+//   line requests of the DMA), and the 2-column-per-lane epilogue halves the store width.
 // M = 12608 gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 /
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
