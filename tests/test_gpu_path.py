@@ -74,7 +74,7 @@ def test_episode(name):
         gref = g["grad/" + k]
         if n_up == 1:
             # (1) gradients: bf16 operands cost ~1e-2 of the tensor max vs the fp32 reference
-            #     (the bf16-emulating oracle shows the same distance, tools/diag_path.py)
+            #     (the bf16-emulating oracle shows the same distance, tests/diag_path.py)
             if np.abs(gref).max() == 0:
                 assert not grads[k].any(), k                     # dA == 0 exactly while B == 0 (Q11)
             else:
@@ -143,7 +143,7 @@ def test_errors_are_loud():
 def test_vit_b16_against_reference_goldens(name):
     """BASELINE configs 1-3 shapes (ViT-B/16, r=16; 8 views/K=10 and 64 views/K=200) vs the outputs
     of the reference itself.  bf16 MFMA operands cost 3-5e-3 of the logit range on this model
-    (the bf16-emulating oracle sits at the same distance: tools/diag_path.py), the selection set
+    (the bf16-emulating oracle sits at the same distance: tests/diag_path.py), the selection set
     is still exactly the reference's."""
     g, cfg, W, x, lora0, tf = load_case(name)
     kw = episode_kwargs(g)

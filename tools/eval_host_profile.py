@@ -7,14 +7,14 @@ import torch
 from ttl_amd import synth, views as V
 from ttl_amd.config import get_config
 from ttl_amd.driver import EpisodePipeline
-from oracle import ttl_oracle as O  # names only (tool, not product)
 
 streams = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 cfg = get_config("ViT-B/16")
 Wt = synth.vision_weights(cfg, 0)
 lora0 = synth.lora_init(cfg, 1)
 tf = torch.from_numpy(synth.text_features(200, cfg.embed, 2))
-names = O.trainable_names(cfg)
+names = [f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight"
+         for i in range(cfg.layer_lo, cfg.layer_hi + 1) for pj in ("q_proj", "v_proj") for ab in ("A", "B")]
 pipe = EpisodePipeline(cfg, Wt, names, lora0, tf, float(np.exp(Wt["logit_scale"])), "cuda:0", n_streams=streams)
 img = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (375, 500, 3), dtype=np.uint8)).pin_memory()
 gen = torch.Generator().manual_seed(0)
