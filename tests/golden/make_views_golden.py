@@ -58,16 +58,16 @@ def main():
         pil = Image.fromarray(img)
         s = min(h, w)
         boxes = [((h - s) // 2, (w - s) // 2, s, s, 2)]      # flags bit1: the base (Resize+CenterCrop) view
-        views = [to_tensor_norm(center_view(pil, S))]
+        views = [np.asarray(center_view(pil, S))]
         for _ in range(5):
             bh, bw = int(rng.integers(max(8, h // 6), h + 1)), int(rng.integers(max(8, w // 6), w + 1))
             top, left = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
             b = (top, left, bh, bw, int(rng.integers(0, 2)))
             boxes.append(b)
-            views.append(to_tensor_norm(crop_view(pil, b, S)))
+            views.append(np.asarray(crop_view(pil, b, S)))
         out[f"{name}_img"] = img
         out[f"{name}_boxes"] = np.asarray(boxes, np.int32)
-        out[f"{name}_views"] = np.stack(views)
+        out[f"{name}_views_u8"] = np.stack(views)          # Pillow's uint8 output [n,S,S,3]; ToTensor+Normalize: to_tensor_norm
     out["names"] = np.asarray([c[0] for c in cases])
     out["size"] = np.int32(S)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "views_pil.npz"), **out)

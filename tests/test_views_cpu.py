@@ -15,13 +15,21 @@ def _fixture():
     return np.load(f"{GOLDEN}/views_pil.npz")
 
 
+def normalized(u8):
+    """ToTensor + Normalize (ttl.py:232-234) of Pillow's uint8 views [n,S,S,3] -> fp32 [n,3,S,S]."""
+    a = u8.astype(np.float32) / np.float32(255.0)
+    a = (a - np.asarray(V.CLIP_MEAN, np.float32)) / np.asarray(V.CLIP_STD, np.float32)
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+
+
 def test_oracle_is_bit_exact_with_pillow_fixture():
     g = _fixture()
     S = int(g["size"])
     for n in g["names"]:
+        u8 = np.stack([VO.view_u8(g[f"{n}_img"], b, S) for b in g[f"{n}_boxes"]])
+        assert np.array_equal(u8, g[f"{n}_views_u8"]), n                      # the resampler, byte for byte
         got = VO.make_views(g[f"{n}_img"], g[f"{n}_boxes"], S, V.CLIP_MEAN, V.CLIP_STD)
-        assert got.dtype == np.float32 and got.shape == g[f"{n}_views"].shape
-        assert np.array_equal(got, g[f"{n}_views"]), n
+        assert got.dtype == np.float32 and np.array_equal(got, normalized(g[f"{n}_views_u8"])), n
 
 
 def test_oracle_matches_live_pillow_when_available():
