@@ -572,6 +572,58 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
+        if (i == c->L - 1 && !c->text) {
+            // ---- last layer of the image tower: the head reads its CLS row only (HF modeling_clip.py: pooled =
+            // last_hidden_state[:, 0]), so beyond K and V of every token everything runs on the n CLS rows: the query
+            // projection, attention for query 0, out_proj, LN2 and the MLP.  Row pitch T*D (T*F, T*ldx1) addresses the
+            // CLS rows in place, so the saved activations sit where the CLS-only backward reads them.  Identical
+            // logits; 155 of the 2263 GFLOP of a 64-view forward disappear.
+            const int Kq = tr ? D + 64 : D;
+            {
+                GemmArgs a = {};   // K and V for all tokens: rows D..3D of the [3D][ldw] weight image
+                a.A = x1; a.lda = ldx1; a.B = l.wqkv + (size_t)D * c->ldw; a.ldb = c->ldw; a.M = M; a.N = 2 * D; a.K = Kq;
+                a.C = qkv + D; a.ldc = 3 * D; a.bias = l.bqkv + D;
+                if ((rc = gemm(c, EPI_OP, a, s))) return rc;
+            }
+            {
+                GemmArgs a = {};   // Q for the CLS rows
+                a.A = x1; a.lda = T * ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = n; a.N = D; a.K = Kq;
+                a.C = qkv; a.ldc = T * 3 * D; a.bias = l.bqkv;
+                if ((rc = gemm(c, EPI_OP, a, s))) return rc;
+            }
+            {
+                Prof p(c, 1, s);
+                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s));
+            }
+            float* h_mid = tr ? l.h_mid : h_in;
+            {
+                GemmArgs a = {};
+                a.A = att; a.lda = T * D; a.B = l.wo; a.ldb = D; a.M = n; a.N = D; a.K = D;
+                a.C = h_mid; a.ldc = T * D; a.bias = l.bo; a.resid = h_in; a.ldr = T * D;
+                if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
+            }
+            {
+                Prof p(c, 3, s);   // statistics of the CLS rows are stored compactly: [n]
+                HIP_TRY(launch_layernorm(h_mid, (long long)T * D, l.ln2g, l.ln2b, nullptr, c->x2, D, sv ? l.mu2 : nullptr,
+                                         sv ? l.rs2 : nullptr, n, D, c->c.ln_eps, s));
+            }
+            {
+                GemmArgs a = {};
+                a.A = c->x2; a.lda = D; a.B = l.w1; a.ldb = D; a.M = n; a.N = F; a.K = D;
+                a.C = c->g; a.ldc = F; a.bias = l.b1; a.C2 = sv ? l.u : nullptr; a.ldc2 = T * F;
+                if ((rc = gemm(c, EPI_GELU, a, s))) return rc;
+            }
+            float* h_next = tr ? c->h_out[i - c->c.layer_lo] : h_mid;
+            {
+                GemmArgs a = {};
+                a.A = c->g; a.lda = F; a.B = l.w2; a.ldb = F; a.M = n; a.N = D; a.K = F;
+                a.C = h_next; a.ldc = T * D; a.bias = l.b2; a.resid = h_mid; a.ldr = T * D;
+                if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
+            }
+            if (tr) l.h_in = h_in;
+            h = h_next;
+            continue;
+        }
         {
             GemmArgs a = {};
             a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = tr ? D + 64 : D;
@@ -697,7 +749,7 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             // the end-of-text position differs per prompt, so the text tower gathers them into compact copies
             const op_t* u_rows = l.u; int ld_u = T * F;
             const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
-            const float *mu2 = l.mu2, *rs2 = l.rs2; int stat_pitch = T;
+            const float *mu2 = l.mu2, *rs2 = l.rs2; int stat_pitch = 1;   // the CLS-only forward stores them as [n]
             if (pool) {
                 Prof p(c, 3, s);
                 HIP_TRY(launch_gather_rows_op(l.u, F, pool, T, c->u_g, n, F, s));

@@ -427,6 +427,71 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
     }
 }
 
+// ------------------------------------------------------------------------------ forward, CLS query only
+// Last encoder layer of the image tower: only its CLS row reaches the head, so only query 0 of every (view, head)
+// is needed: o_0 = softmax(q_0 K^T / 8) V.  Same rounding points as the dense kernel (P rounded to the operand type
+// before the PV product, row sum taken before rounding); writes row 0 of `out` and lse[.., 0] in place.
+__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out, int ldo,
+                                                           float* __restrict__ lse, int T, int H) {
+    __shared__ float sq[64], sp[320], sred[32][64];
+    __shared__ float smax[4], ssum[4];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / H, head = blockIdx.x - img * H;
+    const int D = H * 64;
+    const op_t* base = qkv + (size_t)img * T * ld + head * 64;
+    if (tid < 64) sq[tid] = op_to_f32(base[tid]);
+    __syncthreads();
+    const int c = tid & 7, grp = tid >> 3;            // 8 lanes per key, lane c owns head-dim chunk c
+    float qc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qc[e] = sq[8 * c + e];
+    // pass 1: raw scores -> LDS, running max
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        const int j = j0 + grp;
+        const int jr = j < T ? j : T - 1;
+        opx8 kf = *(const opx8*)(base + (size_t)jr * ld + D + 8 * c);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(qc[e], (float)kf[e], s);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (j < T) { if (c == 0) sp[j] = s; mx = fmaxf(mx, s); }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) smax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    // pass 2: p = exp((s - max)/8), sum, o += round(p) * v
+    float sum = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        const int j = j0 + grp;
+        if (j < T) {
+            const float pj = __expf((sp[j] - mx) * SCALE);
+            if (c == 0) sum += pj;
+            const float pb = op_to_f32(f32_to_op(pj));
+            opx8 vf = *(const opx8*)(base + (size_t)j * ld + 2 * D + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, (float)vf[e], o[e]);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) ssum[tid >> 6] = sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sred[grp][8 * c + e] = o[e];
+    __syncthreads();
+    sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    if (tid < 64) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) v += sred[g][tid];
+        out[(size_t)img * T * ldo + head * 64 + tid] = f32_to_op(v / sum);
+        if (tid == 0 && lse) lse[((size_t)img * H + head) * T] = mx * SCALE + __logf(sum);
+    }
+}
+
 // ------------------------------------------------------------------------------ backward, CLS query only
 // Top layer: the loss reads only the CLS token, so d(out) is non-zero for query 0 alone and the
 // whole backward of a (view, head) collapses to rank-1 work (SURVEY appendix A with q = q_0):
@@ -584,6 +649,13 @@ hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, co
     if (nkt <= 7) return bwd_t<7>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
     if (nkt <= 9) return bwd_t<9>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
+                                    hipStream_t s) {
+    if (T > 320) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H);
+    return hipGetLastError();
 }
 
 hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,

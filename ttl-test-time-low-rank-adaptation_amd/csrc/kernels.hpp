@@ -78,6 +78,9 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
 hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s, int causal = 0);
+// Forward for query 0 of every sequence only (last image-tower layer): writes row n*T of `out` and lse[n][h][0].
+hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
+                                    hipStream_t s);
 // Same gradients when d(out) is non-zero only for ONE query of every sequence (the top layer): token 0
 // (CLS) or, with qpos != null, token qpos[sequence] (end-of-text).  dout_cls bf16 [n][H*64]; writes dense
 // dq (zero rows for every other token), dk, dv.
