@@ -216,7 +216,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach1, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per GEMM launch",
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                "kernel": "gemm_kernel<160,2,2,2,EPI,false> + <128,2,2,4,EPI,true>: all GEMM launches of an episode",
+                "kernel": "gemm_kernel<160,2,2,2,EPI,false>: every big-M (M >= 1024) GEMM launch of an episode; the small-M "
+                          "launches (1-view inference, CLS-row GEMMs of the last layer) are class gemm_small_m",
                 "regime": "one episode at a time (kernel alone on the chip; HIP events on the launch stream)",
                 "flops_per_launch": round(gflops1 / max(cnt1["gemm"], 1)),
                 "avg_launch_us": round(1e3 * ms1["gemm"] / max(cnt1["gemm"], 1), 2),

@@ -219,9 +219,11 @@ int ttl_make_views(const unsigned char* image_hwc, int height, int width, const 
 int ttl_debug_copy(ttl_ctx* ctx, const char* name, int layer, void* host_dst, size_t bytes);
 
 /* Per-kernel-class device time of the calls made while profiling is on (HIP events on `stream`).
- * classes: 0 gemm, 1 attention fwd, 2 attention bwd, 3 layernorm/elementwise, 4 lora, 5 head/loss/opt.
+ * classes: 0 gemm (the big-M 160x128 kernel: M >= 1024), 1 attention fwd, 2 attention bwd, 3 layernorm/elementwise,
+ * 4 lora, 5 head/loss/opt, 6 small-M gemm (1-view inference, CLS-row GEMMs: latency-bound 128x128 launches).
+ * gemm_flops / ttl_profile_gemm_bytes cover class 0 only.
  * ttl_profile_read synchronises and returns accumulated milliseconds and launch counts. */
-#define TTL_NCLASS 6
+#define TTL_NCLASS 7
 int ttl_profile_enable(ttl_ctx* ctx, int on);
 int ttl_profile_read(ttl_ctx* ctx, double ms[TTL_NCLASS], long long launches[TTL_NCLASS],
                      double* gemm_flops);

@@ -18,6 +18,8 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             m = re.search(r"gemm_kernel<([^>]*)>", r["Kernel_Name"])
+            if m and not m.group(1).startswith("160"):
+                continue                      # the roofline is for the big-M 160x128 kernel; small-M launches are their own class
             by["gemm_kernel<%s>" % (m.group(1) if m else "?")].append(float(r["Counter_Value"]))
     return by
 

@@ -183,11 +183,12 @@ struct Prof {
 };
 
 int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
-    Prof p(c, 0, s);
+    const bool big = a0.M >= 1024;   // launch_gemm's own split: the 160x128 kernel vs the latency-bound small-M path
+    Prof p(c, big ? 0 : 6, s);
     GemmArgs a = a0;
     a.padded = 1;   // every arena buffer has Mmax = round_up(N*T, 320) rows
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
-    if (c->prof) {
+    if (c->prof && big) {
         c->gemm_flops += 2.0 * a.M * a.N * a.K;
         // algorithmic bytes of the launch: both operands once, every output once, the fused epilogue inputs once
         const double mn = (double)a.M * a.N;

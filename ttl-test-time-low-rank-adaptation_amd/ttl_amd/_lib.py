@@ -17,8 +17,8 @@ HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ttl_h
 
 TTL_SEL_LE_THRESH = 0
 TTL_SEL_TOPK = 1
-TTL_NCLASS = 6
-PROFILE_CLASSES = ("gemm", "attention_fwd", "attention_bwd", "layernorm_elementwise", "lora", "head_loss_opt")
+TTL_NCLASS = 7
+PROFILE_CLASSES = ("gemm", "attention_fwd", "attention_bwd", "layernorm_elementwise", "lora", "head_loss_opt", "gemm_small_m")
 
 
 class TtlError(RuntimeError):
