@@ -31,79 +31,78 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
-// ---- head forward: (LayerNorm of the CLS rows is launch_layernorm) -> projection -> logits
-// grid (ceil(E/HB), n): thread e accumulates over D with coalesced WpT reads, y row staged in LDS
+// ---- head forward / backward mat-vecs.  All four are  out[v][o] = post( sum_i in[v][i] * W[i][o] )  with W row-major
+// [I][O] (coalesced over o).  One block = 64 outputs x 4 slices of the reduction (256 threads): each thread walks I/4
+// terms with four independent chains, the slices meet in LDS.  (One thread per output walking all I terms left
+// 128 blocks of a 64-view call latency-bound at 23-33 us per launch.)
+constexpr int HO = 64;   // outputs per block
+
+template <typename F>
+__device__ __forceinline__ float matvec64(const float* __restrict__ in_lds, const float* __restrict__ W, int I, int O, int o, int slice,
+                                          float (*part)[HO], F&& post_unused) {
+    (void)post_unused;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (o < O) {
+        const float* w = W + o;
+        int i = slice;
+#pragma unroll 2
+        for (; i + 12 < I; i += 16) {
+            a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
+            a1 = fmaf(in_lds[i + 4], w[(size_t)(i + 4) * O], a1);
+            a2 = fmaf(in_lds[i + 8], w[(size_t)(i + 8) * O], a2);
+            a3 = fmaf(in_lds[i + 12], w[(size_t)(i + 12) * O], a3);
+        }
+        for (; i < I; i += 4) a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
+    }
+    part[slice][threadIdx.x & (HO - 1)] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    return (part[0][threadIdx.x & (HO - 1)] + part[1][threadIdx.x & (HO - 1)]) +
+           (part[2][threadIdx.x & (HO - 1)] + part[3][threadIdx.x & (HO - 1)]);
+}
+
+// grid (ceil(E/64), n): f[v][e] = sum_d y[v][d] * WpT[d][e]
 __global__ __launch_bounds__(HB) void head_proj_kernel(HeadArgs a) {
     extern __shared__ float sm[];
-    const int v = blockIdx.y, e = blockIdx.x * HB + threadIdx.x;
+    __shared__ float part[4][HO];
+    const int v = blockIdx.y, e = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < a.D; d += HB) sm[d] = a.y[(size_t)v * a.D + d];
     __syncthreads();
-    if (e >= a.E) return;
-    // 4 independent chains x unroll: keeps ~16 loads in flight per thread (latency-bound otherwise)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* w = a.WpT + e;
-    int d = 0;
-#pragma unroll 4
-    for (; d + 4 <= a.D; d += 4) {
-        a0 = fmaf(sm[d], w[(size_t)d * a.E], a0);
-        a1 = fmaf(sm[d + 1], w[(size_t)(d + 1) * a.E], a1);
-        a2 = fmaf(sm[d + 2], w[(size_t)(d + 2) * a.E], a2);
-        a3 = fmaf(sm[d + 3], w[(size_t)(d + 3) * a.E], a3);
+    const float acc = matvec64(sm, a.WpT, a.D, a.E, e, slice, part, 0);
+    if (slice == 0 && e < a.E) {
+        a.f[(size_t)v * a.E + e] = acc;
+        if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
     }
-    for (; d < a.D; ++d) a0 = fmaf(sm[d], w[(size_t)d * a.E], a0);
-    const float acc = (a0 + a1) + (a2 + a3);
-    a.f[(size_t)v * a.E + e] = acc;
-    if (a.feats_out) a.feats_out[(size_t)v * a.E + e] = acc;
 }
-// grid (ceil(K/HB), n): z[v][k] = scale * <f/||f||, t_k>
+// grid (ceil(K/64), n): z[v][k] = scale * <f/||f||, t_k>
 __global__ __launch_bounds__(HB) void head_logits_kernel(HeadArgs a) {
     extern __shared__ float sm[];
     __shared__ float red[HB / 64];
-    const int v = blockIdx.y, k = blockIdx.x * HB + threadIdx.x;
+    __shared__ float part[4][HO];
+    const int v = blockIdx.y, k = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     float nn = 0.f;
     for (int e = threadIdx.x; e < a.E; e += HB) { float t = a.f[(size_t)v * a.E + e]; sm[e] = t; nn += t * t; }
     const float inv = a.scale / sqrtf(block_sum(nn, red));
-    if (k >= a.K) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* w = a.tfeatT + k;
-    int e = 0;
-#pragma unroll 4
-    for (; e + 4 <= a.E; e += 4) {
-        a0 = fmaf(sm[e], w[(size_t)e * a.K], a0);
-        a1 = fmaf(sm[e + 1], w[(size_t)(e + 1) * a.K], a1);
-        a2 = fmaf(sm[e + 2], w[(size_t)(e + 2) * a.K], a2);
-        a3 = fmaf(sm[e + 3], w[(size_t)(e + 3) * a.K], a3);
-    }
-    for (; e < a.E; ++e) a0 = fmaf(sm[e], w[(size_t)e * a.K], a0);
-    a.logits[(size_t)v * a.K + k] = ((a0 + a1) + (a2 + a3)) * inv;
+    const float acc = matvec64(sm, a.tfeatT, a.E, a.K, k, slice, part, 0);
+    if (slice == 0 && k < a.K) a.logits[(size_t)v * a.K + k] = acc * inv;
 }
 // ---- head backward
-// grid (ceil(E/HB), n): dfh[v][e] = scale * sum_k dz[v][k] t[k][e]
+// grid (ceil(E/64), n): dfh[v][e] = scale * sum_k dz[v][k] t[k][e]
 __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* __restrict__ dz) {
     extern __shared__ float sm[];
-    const int v = blockIdx.y, e = blockIdx.x * HB + threadIdx.x;
+    __shared__ float part[4][HO];
+    const int v = blockIdx.y, e = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < a.K; k += HB) sm[k] = dz[(size_t)v * a.K + k];
     __syncthreads();
-    if (e >= a.E) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* w = a.tfeat + e;
-    int k = 0;
-#pragma unroll 4
-    for (; k + 4 <= a.K; k += 4) {
-        a0 = fmaf(sm[k], w[(size_t)k * a.E], a0);
-        a1 = fmaf(sm[k + 1], w[(size_t)(k + 1) * a.E], a1);
-        a2 = fmaf(sm[k + 2], w[(size_t)(k + 2) * a.E], a2);
-        a3 = fmaf(sm[k + 3], w[(size_t)(k + 3) * a.E], a3);
-    }
-    for (; k < a.K; ++k) a0 = fmaf(sm[k], w[(size_t)k * a.E], a0);
+    const float acc = matvec64(sm, a.tfeat, a.K, a.E, e, slice, part, 0);
     // TTL_GRAD_SCALE: fixed loss scale of the fp16 build (1 for bf16), removed again in wgrad_reduce_kernel
-    a.tmp_e[(size_t)v * a.E + e] = ((a0 + a1) + (a2 + a3)) * a.scale * TTL_GRAD_SCALE;
+    if (slice == 0 && e < a.E) a.tmp_e[(size_t)v * a.E + e] = acc * a.scale * TTL_GRAD_SCALE;
 }
-// grid (ceil(D/HB), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
+// grid (ceil(D/64), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
 __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
     extern __shared__ float sm[];
     __shared__ float red[HB / 64];
-    const int v = blockIdx.y, d = blockIdx.x * HB + threadIdx.x;
+    __shared__ float part[4][HO];
+    const int v = blockIdx.y, d = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     const float* f = a.f + (size_t)v * a.E;
     const float* dfh = a.tmp_e + (size_t)v * a.E;
     float nn = 0.f;
@@ -114,19 +113,8 @@ __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
     dot = block_sum(dot, red);
     for (int e = threadIdx.x; e < a.E; e += HB) sm[e] = (dfh[e] - (f[e] / nrm) * dot) / nrm;
     __syncthreads();
-    if (d >= a.D) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* w = a.Wp + d;
-    int e = 0;
-#pragma unroll 4
-    for (; e + 4 <= a.E; e += 4) {
-        a0 = fmaf(sm[e], w[(size_t)e * a.D], a0);
-        a1 = fmaf(sm[e + 1], w[(size_t)(e + 1) * a.D], a1);
-        a2 = fmaf(sm[e + 2], w[(size_t)(e + 2) * a.D], a2);
-        a3 = fmaf(sm[e + 3], w[(size_t)(e + 3) * a.D], a3);
-    }
-    for (; e < a.E; ++e) a0 = fmaf(sm[e], w[(size_t)e * a.D], a0);
-    a.tmp_d[(size_t)v * a.D + d] = (a0 + a1) + (a2 + a3);
+    const float acc = matvec64(sm, a.Wp, a.E, a.D, d, slice, part, 0);
+    if (slice == 0 && d < a.D) a.tmp_d[(size_t)v * a.D + d] = acc;
 }
 
 // ---- loss, pass 1: one block per view: row softmax statistics -> H_i, lse_i
@@ -326,14 +314,14 @@ hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
     hipError_t e = launch_layernorm(a.h, (long long)a.T * a.D, a.ln_g, a.ln_b, a.y, nullptr, 0, a.cls_mean, a.cls_rstd, n, a.D,
                                     a.eps, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(head_proj_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.D * sizeof(float), s, a);
-    if (a.K > 0) hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
+    hipLaunchKernelGGL(head_proj_kernel, dim3((a.E + HO - 1) / HO, n), dim3(HB), a.D * sizeof(float), s, a);
+    if (a.K > 0) hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HO - 1) / HO, n), dim3(HB), a.E * sizeof(float), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, op_t* dh16, int n, hipStream_t s) {
-    hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HB - 1) / HB, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
-    hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HB - 1) / HB, n), dim3(HB), a.E * sizeof(float), s, a);
+    hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HO - 1) / HO, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
+    hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HO - 1) / HO, n), dim3(HB), a.E * sizeof(float), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // LayerNorm backward on the CLS rows -> compact [n, D]
