@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
-    ap.add_argument("--streams", type=int, default=2, help="independent episodes in flight per GPU (HIP streams)")
+    ap.add_argument("--streams", type=int, default=3, help="independent episodes in flight per GPU (HIP streams)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="MFMA operand dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -20,7 +20,7 @@ dev = torch.device("cuda:0")
 views = [torch.from_numpy(synth.views(vcfg, 64, 1000 + j)).to(dev) for j in range(4)]
 for K in (200, 1000):
     ids = synth.token_ids(K, tcfg, 3)
-    for streams in (1, 2):
+    for streams in (1, 2, 3):
         fac = lambda: build_text_mode_engine(vcfg, tcfg, Wv, Wt, ids, 100.0, dev, 64, K)
         pipe = EpisodePipeline(vcfg, None, names, lora, None, 100.0, dev, n_streams=streams, max_views=64, engine_factory=fac, n_classes=K)
         for i in range(6):

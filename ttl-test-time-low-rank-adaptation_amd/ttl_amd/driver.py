@@ -75,8 +75,8 @@ class EpisodePipeline:
 
     Episodes of different test images share nothing but the frozen weights (ttl.py:338-344 resets
     LoRA + Adam state per image), so the launch tails, small kernels and HBM-bound phases of one
-    image overlap with the MFMA-bound phases of another: +18 % images/s at S = 2 on MI355X
-    (tools/two_stream_bench.py).  Every slot owns a context (its activation arena), its LoRA /
+    image overlap with the MFMA-bound phases of another: +19 % images/s at S = 2 and +23 % at S = 3 on
+    MI355X (S = 4 is slower again; bench.py --streams).  Every slot owns a context (its activation arena), its LoRA /
     gradient / Adam buffers and a stream; results are identical to running the slots one by one.
     """
 

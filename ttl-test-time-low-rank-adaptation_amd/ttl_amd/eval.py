@@ -32,7 +32,7 @@ def episode_kwargs_from_args(args):
                 reweight=float(getattr(args, "reweight_ent", 1)), lr=args.lr)
 
 
-def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state, scaler, args, n_streams=2,
+def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state, scaler, args, n_streams=3,
                          rank=0, world=1, gpu_augmenter=None):
     """Same call shape as ttl.py:300.  ``val_loader`` yields (images, target) with images either a
     list of [1,3,S,S] tensors (view 0 first, like AugMixAugmenter) or one [N,3,S,S] tensor — or, with
@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--deyo_selection", default=True)
     ap.add_argument("--deyo_margin_e0", type=float, default=0.4)
     ap.add_argument("--reweight_ent", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
