@@ -84,7 +84,7 @@ struct ttl_ctx {
     // text tower (c.tower == TTL_TOWER_TEXT): token table, prompt ids, pooled (end-of-text) positions and the
     // compact copies of the pooled rows the top-layer backward reads; logits in [views, prompts] order
     int text = 0;
-    float* tok = nullptr; int* ids = nullptr; int* pool = nullptr; int n_prompts = 0;
+    float* tok = nullptr; int* ids = nullptr; int* pool = nullptr; int* poolrows = nullptr; int n_prompts = 0;
     float *hpool = nullptr, *hmid_g = nullptr, *mu2_g = nullptr, *rs2_g = nullptr; op_t* u_g = nullptr;
     float *logits_nk = nullptr, *dlogits_nk = nullptr, *dlogits_kn = nullptr;
     // peer features (image tower: class-text features; text tower: the image features of the views)
@@ -261,7 +261,7 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->wpatch, D * c->Kp, true);
     if (c->text) {
         ALLOC(c->tok, (size_t)k->vocab_size * D, false);
-        ALLOC(c->ids, N * T, true); ALLOC(c->pool, N, true);
+        ALLOC(c->ids, N * T, true); ALLOC(c->pool, N, true); ALLOC(c->poolrows, N, true);
         ALLOC(c->hpool, N * D, true); ALLOC(c->hmid_g, N * D, false); ALLOC(c->mu2_g, N, false); ALLOC(c->rs2_g, N, false);
         ALLOC(c->u_g, N * F, false);
         ALLOC(c->logits_nk, N * k->max_classes, false); ALLOC(c->dlogits_nk, N * k->max_classes, false);
@@ -458,7 +458,7 @@ int ttl_set_prompts(ttl_ctx* c, const int* ids, int n_prompts, void* stream) {
     if (n_prompts < 1 || n_prompts > c->c.max_views) return fail(TTL_EINVAL, "n_prompts %d outside [1,%d]", n_prompts, c->c.max_views);
     hipStream_t s = (hipStream_t)stream;
     const size_t cnt = (size_t)n_prompts * c->T;
-    std::vector<int> host(cnt), pool(n_prompts);
+    std::vector<int> host(cnt), pool(n_prompts), rows(n_prompts);
     HIP_TRY(hipMemcpy(host.data(), ids, cnt * sizeof(int), hipMemcpyDefault));
     for (int p = 0; p < n_prompts; ++p) {
         // pooled position = argmax of the ids (first maximum), HF CLIPTextTransformer with eos_token_id == 2
@@ -469,9 +469,11 @@ int ttl_set_prompts(ttl_ctx* c, const int* ids, int n_prompts, void* stream) {
             if (v > host[(size_t)p * c->T + best]) best = t;
         }
         pool[p] = best;
+        rows[p] = p * c->T + best;   // row of the pooled token in the [n*T, .] activation buffers
     }
     HIP_TRY(hipMemcpyAsync(c->ids, host.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->pool, pool.data(), n_prompts * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->poolrows, rows.data(), n_prompts * sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // the host vectors go out of scope
     c->n_prompts = n_prompts;
     return 0;
@@ -573,12 +575,15 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
-        if (i == c->L - 1 && !c->text) {
-            // ---- last layer of the image tower: the head reads its CLS row only (HF modeling_clip.py: pooled =
-            // last_hidden_state[:, 0]), so beyond K and V of every token everything runs on the n CLS rows: the query
-            // projection, attention for query 0, out_proj, LN2 and the MLP.  Row pitch T*D (T*F, T*ldx1) addresses the
-            // CLS rows in place, so the saved activations sit where the CLS-only backward reads them.  Identical
-            // logits; 155 of the 2263 GFLOP of a 64-view forward disappear.
+        if (i == c->L - 1 && (!c->text || n < 1024)) {   // (row maps exist in the small-M GEMM kernels only)
+            // ---- last layer: the head reads ONE row per sequence (image tower: CLS, HF modeling_clip.py pooled =
+            // last_hidden_state[:, 0]; text tower: the end-of-text token), so beyond K and V of every token everything
+            // runs on those n rows: the query projection, attention for that query, out_proj, LN2 and the MLP — in place,
+            // so the saved activations sit where the pooled-row backward reads them.  Image tower: the CLS rows have the
+            // fixed pitch T*D (T*F, T*ldx1); text tower: row maps (poolrows[v] = v*T + eot position).  Identical logits;
+            // 155 of the 2263 GFLOP of a 64-view image forward disappear.
+            const int* map = c->text ? c->poolrows : nullptr;
+            const long long pitch = map ? 1 : T;                  // row pitch multiplier when addressing by stride
             const int Kq = tr ? D + 64 : D;
             {
                 GemmArgs a = {};   // K and V for all tokens: rows D..3D of the [3D][ldw] weight image
@@ -587,38 +592,38 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
                 if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
-                GemmArgs a = {};   // Q for the CLS rows
-                a.A = x1; a.lda = T * ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = n; a.N = D; a.K = Kq;
-                a.C = qkv; a.ldc = T * 3 * D; a.bias = l.bqkv;
+                GemmArgs a = {};   // Q for the pooled rows
+                a.A = x1; a.lda = (int)(pitch * ldx1); a.B = l.wqkv; a.ldb = c->ldw; a.M = n; a.N = D; a.K = Kq;
+                a.C = qkv; a.ldc = (int)(pitch * 3 * D); a.bias = l.bqkv; a.amap = map; a.cmap = map;
                 if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
                 Prof p(c, 1, s);
-                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s));
+                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s, c->text ? c->pool : nullptr, causal));
             }
             float* h_mid = tr ? l.h_mid : h_in;
             {
                 GemmArgs a = {};
-                a.A = att; a.lda = T * D; a.B = l.wo; a.ldb = D; a.M = n; a.N = D; a.K = D;
-                a.C = h_mid; a.ldc = T * D; a.bias = l.bo; a.resid = h_in; a.ldr = T * D;
+                a.A = att; a.lda = (int)(pitch * D); a.B = l.wo; a.ldb = D; a.M = n; a.N = D; a.K = D;
+                a.C = h_mid; a.ldc = (int)(pitch * D); a.bias = l.bo; a.resid = h_in; a.ldr = (int)(pitch * D); a.amap = map; a.cmap = map;
                 if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
             }
             {
-                Prof p(c, 3, s);   // statistics of the CLS rows are stored compactly: [n]
-                HIP_TRY(launch_layernorm(h_mid, (long long)T * D, l.ln2g, l.ln2b, nullptr, c->x2, D, sv ? l.mu2 : nullptr,
-                                         sv ? l.rs2 : nullptr, n, D, c->c.ln_eps, s));
+                Prof p(c, 3, s);   // statistics of the pooled rows are stored compactly: [n]
+                HIP_TRY(launch_layernorm(h_mid, pitch * D, l.ln2g, l.ln2b, nullptr, c->x2, D, sv ? l.mu2 : nullptr,
+                                         sv ? l.rs2 : nullptr, n, D, c->c.ln_eps, s, map));
             }
             {
                 GemmArgs a = {};
                 a.A = c->x2; a.lda = D; a.B = l.w1; a.ldb = D; a.M = n; a.N = F; a.K = D;
-                a.C = c->g; a.ldc = F; a.bias = l.b1; a.C2 = sv ? l.u : nullptr; a.ldc2 = T * F;
+                a.C = c->g; a.ldc = F; a.bias = l.b1; a.C2 = sv ? l.u : nullptr; a.ldc2 = (int)(pitch * F); a.c2map = map;
                 if ((rc = gemm(c, EPI_GELU, a, s))) return rc;
             }
             float* h_next = tr ? c->h_out[i - c->c.layer_lo] : h_mid;
             {
                 GemmArgs a = {};
                 a.A = c->g; a.lda = F; a.B = l.w2; a.ldb = F; a.M = n; a.N = D; a.K = F;
-                a.C = h_next; a.ldc = T * D; a.bias = l.b2; a.resid = h_mid; a.ldr = T * D;
+                a.C = h_next; a.ldc = (int)(pitch * D); a.bias = l.b2; a.resid = h_mid; a.ldr = (int)(pitch * D); a.cmap = map;
                 if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
             }
             if (tr) l.h_in = h_in;
@@ -750,14 +755,18 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             // the end-of-text position differs per prompt, so the text tower gathers them into compact copies
             const op_t* u_rows = l.u; int ld_u = T * F;
             const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
-            const float *mu2 = l.mu2, *rs2 = l.rs2; int stat_pitch = 1;   // the CLS-only forward stores them as [n]
+            const float *mu2 = l.mu2, *rs2 = l.rs2;
+            const int stat_pitch = 1;   // the pooled-row forward stores them as [n]
             if (pool) {
                 Prof p(c, 3, s);
                 HIP_TRY(launch_gather_rows_op(l.u, F, pool, T, c->u_g, n, F, s));
                 HIP_TRY(launch_gather_rows_f32(l.h_mid, D, pool, T, c->hmid_g, n, D, s));
-                HIP_TRY(launch_gather_rows_f32(l.mu2, 1, pool, T, c->mu2_g, n, 1, s));
-                HIP_TRY(launch_gather_rows_f32(l.rs2, 1, pool, T, c->rs2_g, n, 1, s));
-                u_rows = c->u_g; ld_u = F; hmid_rows = c->hmid_g; hmid_pitch = D; mu2 = c->mu2_g; rs2 = c->rs2_g; stat_pitch = 1;
+                u_rows = c->u_g; ld_u = F; hmid_rows = c->hmid_g; hmid_pitch = D;
+                if (n >= 1024) {   // dense last layer (no row maps at this size): statistics sit at every row
+                    HIP_TRY(launch_gather_rows_f32(l.mu2, 1, pool, T, c->mu2_g, n, 1, s));
+                    HIP_TRY(launch_gather_rows_f32(l.rs2, 1, pool, T, c->rs2_g, n, 1, s));
+                    mu2 = c->mu2_g; rs2 = c->rs2_g;
+                }
             }
             {
                 GemmArgs a = {};

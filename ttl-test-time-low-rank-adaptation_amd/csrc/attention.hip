@@ -432,14 +432,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
 // is needed: o_0 = softmax(q_0 K^T / 8) V.  Same rounding points as the dense kernel (P rounded to the operand type
 // before the PV product, row sum taken before rounding); writes row 0 of `out` and lse[.., 0] in place.
 __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out, int ldo,
-                                                           float* __restrict__ lse, int T, int H) {
+                                                           float* __restrict__ lse, int T, int H, const int* __restrict__ qpos,
+                                                           int causal) {
     __shared__ float sq[64], sp[320], sred[32][64];
     __shared__ float smax[4], ssum[4];
     const int tid = threadIdx.x;
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
     const int D = H * 64;
     const op_t* base = qkv + (size_t)img * T * ld + head * 64;
-    if (tid < 64) sq[tid] = op_to_f32(base[tid]);
+    const int qp = qpos ? qpos[img] : 0;              // the pooled query: CLS, or the end-of-text token (text tower)
+    const int Tk = causal ? qp + 1 : T;               // keys it can see
+    if (tid < 64) sq[tid] = op_to_f32(base[(size_t)qp * ld + tid]);
     __syncthreads();
     const int c = tid & 7, grp = tid >> 3;            // 8 lanes per key, lane c owns head-dim chunk c
     float qc[8];
@@ -447,16 +450,16 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
     for (int e = 0; e < 8; ++e) qc[e] = sq[8 * c + e];
     // pass 1: raw scores -> LDS, running max
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < T; j0 += 32) {
+    for (int j0 = 0; j0 < Tk; j0 += 32) {
         const int j = j0 + grp;
-        const int jr = j < T ? j : T - 1;
+        const int jr = j < Tk ? j : Tk - 1;
         opx8 kf = *(const opx8*)(base + (size_t)jr * ld + D + 8 * c);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(qc[e], (float)kf[e], s);
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o, 64);
-        if (j < T) { if (c == 0) sp[j] = s; mx = fmaxf(mx, s); }
+        if (j < Tk) { if (c == 0) sp[j] = s; mx = fmaxf(mx, s); }
     }
     mx = wave_max(mx);
     if ((tid & 63) == 0) smax[tid >> 6] = mx;
@@ -466,9 +469,9 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
     float sum = 0.f, o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j0 = 0; j0 < T; j0 += 32) {
+    for (int j0 = 0; j0 < Tk; j0 += 32) {
         const int j = j0 + grp;
-        if (j < T) {
+        if (j < Tk) {
             const float pj = __expf((sp[j] - mx) * SCALE);
             if (c == 0) sum += pj;
             const float pb = op_to_f32(f32_to_op(pj));
@@ -487,8 +490,8 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
         float v = 0.f;
 #pragma unroll 8
         for (int g = 0; g < 32; ++g) v += sred[g][tid];
-        out[(size_t)img * T * ldo + head * 64 + tid] = f32_to_op(v / sum);
-        if (tid == 0 && lse) lse[((size_t)img * H + head) * T] = mx * SCALE + __logf(sum);
+        out[((size_t)img * T + qp) * ldo + head * 64 + tid] = f32_to_op(v / sum);
+        if (tid == 0 && lse) lse[((size_t)img * H + head) * T + qp] = mx * SCALE + __logf(sum);
     }
 }
 
@@ -652,9 +655,9 @@ hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, co
 }
 
 hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
-                                    hipStream_t s) {
+                                    hipStream_t s, const int* qpos, int causal) {
     if (T > 320) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H);
+    hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H, qpos, causal);
     return hipGetLastError();
 }
 

@@ -87,12 +87,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y32, op_t* __restrict__ y16, int ld16,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int D, float eps) {
+                                                     int D, float eps, const int* __restrict__ rowmap) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
     const int nch = D >> 2;
-    const float* xr = x + (size_t)row * row_stride;
+    const float* xr = x + (size_t)(rowmap ? rowmap[row] : row) * row_stride;
     float4 v[LN_MAXC];
     float s = 0.f;
 #pragma unroll
@@ -231,27 +231,29 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const float* __restrict_
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ resid,
-                                     int ldr, const float* __restrict__ bias, float* __restrict__ out, int ldc) {
+                                     int ldr, const float* __restrict__ bias, float* __restrict__ out, int ldc,
+                                     const int* __restrict__ cmap) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (size_t)M * N) return;
     int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    const int pm = cmap ? cmap[m] : m;   // physical row of resid / out
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (resid) acc = *(const float4*)(resid + (size_t)m * ldr + n);
+    if (resid) acc = *(const float4*)(resid + (size_t)pm * ldr + n);
     if (bias) { float4 b = *(const float4*)(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
     for (int s = 0; s < splits; ++s) {
         float4 p = *(const float4*)(part + (size_t)s * M * N + i);
         acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
     }
-    *(float4*)(out + (size_t)m * ldc + n) = acc;
+    *(float4*)(out + (size_t)pm * ldc + n) = acc;
 }
 
 }  // namespace
 
 hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr, const float* bias,
-                                float* out, int ldc, hipStream_t s) {
+                                float* out, int ldc, hipStream_t s, const int* cmap) {
     size_t n4 = (size_t)M * N / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, splits, M, N, resid, ldr,
-                       bias, out, ldc);
+                       bias, out, ldc, cmap);
     return hipGetLastError();
 }
 
@@ -289,10 +291,10 @@ hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, 
 
 hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta, float* y_f32,
                             op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
-                            hipStream_t s) {
+                            hipStream_t s, const int* rowmap) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, y_f32, y_bf16,
-                       ld_bf16, mean, rstd, rows, D, eps);
+                       ld_bf16, mean, rstd, rows, D, eps, rowmap);
     return hipGetLastError();
 }
 

@@ -76,9 +76,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
         for (int r = 0; r < 4; ++r) {
             const int m = rbase + mt * 16 + 4 * lg + r;
             if (GUARD && m >= M) continue;
+            int pc = m, p2 = m;          // physical rows of C / resid and of C2 (row maps: small-M launches only)
+            if constexpr (GUARD) { if (a.cmap) pc = a.cmap[m]; if (a.c2map) p2 = a.c2map[m]; }
             float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
             if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
-                size_t orow = m;
+                size_t orow = pc;
                 if constexpr (EPI == EPI_PATCH) {
                     int img = m / a.G2, p = m - img * a.G2;
                     orow = (size_t)img * a.T + 1 + p;
@@ -86,13 +88,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
                 if constexpr (EPI == EPI_RESID_F32) {
-                    float4 t = *(const float4*)(a.resid + (size_t)m * a.ldr + n0);
+                    float4 t = *(const float4*)(a.resid + (size_t)pc * a.ldr + n0);
                     v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
                 st_out((f32x4*)((float*)a.C + orow * a.ldc + n0), f32x4{v0, v1, v2, v3});
             } else {
                 if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) st_out((u32x2*)(a.C2 + (size_t)m * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+                    if (a.C2) st_out((u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
                 if constexpr (EPI == EPI_GELU_BWD) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
                     v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
                 }
-                st_out((u32x2*)((op_t*)a.C + (size_t)m * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+                st_out((u32x2*)((op_t*)a.C + (size_t)pc * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
             }
         }
     }
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
         int q = i * NTHR + tid, r = q >> 3, p = q & 7;
         int c = p ^ ((r >> 1) & 7);
         int gr = min(row0 + r, M - 1);
+        if constexpr (GUARD) { if (a.amap) gr = a.amap[gr]; }
         aoff[i] = (uint32_t)(((size_t)gr * a.lda + c * 8) * sizeof(op_t));
     }
 #pragma unroll
@@ -392,6 +395,7 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     if (a0.M <= 0 || a0.N % 128 || a0.K % BK || a0.K <= 0 || (a0.lda & 7) || (a0.ldb & 7)) return hipErrorInvalidValue;
+    if ((a0.amap || a0.cmap || a0.c2map) && a0.M >= 1024) return hipErrorInvalidValue;   // row maps: guarded small-M kernels only
     GemmArgs a = a0;
     a.splits = 1;
     // Small-M, long-K, fp32-output calls (fc2 / dx of the 1-view inference and of the CLS-only top-layer
@@ -402,11 +406,11 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
         while (sp > 1 && ((a.K / BK) % sp || (size_t)sp * a.M * a.N * sizeof(float) > a.ws_bytes)) sp >>= 1;
         if (sp > 1) {
             GemmArgs p = a;
-            p.splits = sp; p.C = a.ws; p.ldc = a.N; p.bias = nullptr; p.resid = nullptr;
+            p.splits = sp; p.C = a.ws; p.ldc = a.N; p.bias = nullptr; p.resid = nullptr; p.cmap = nullptr;
             hipError_t e = launch_v<EPI_F32>(p, s);
             if (e != hipSuccess) return e;
             return launch_splitk_reduce(a.ws, sp, a.M, a.N, epi == EPI_RESID_F32 ? a.resid : nullptr, a.ldr, a.bias, (float*)a.C,
-                                        a.ldc, s);
+                                        a.ldc, s, a.cmap);
         }
     }
     switch (epi) {

@@ -28,6 +28,11 @@ struct GemmArgs {
     int splits;                   // internal: K slices of this launch (blockIdx.y)
     int padded;                   // all C/resid/aux/C2 buffers have rows up to round_up(M, 320): unguarded epilogue allowed
     int xc;                       // internal: columns of the 2-D XCD grid (0 = 1-D tile order)
+    // Row maps (small-M launches only, M < 1024): logical row m lives at physical row map[m] of the buffer.
+    // Lets the last text-tower layer run on the pooled (end-of-text) row of every prompt in place.
+    const int* amap;              // A operand rows
+    const int* cmap;              // C and resid rows
+    const int* c2map;             // C2 rows
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
@@ -48,7 +53,7 @@ hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, 
 // (T*D to pick CLS rows).
 hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta,
                             float* y_f32, op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows,
-                            int D, float eps, hipStream_t s);
+                            int D, float eps, hipStream_t s, const int* rowmap = nullptr /* input row r = x row rowmap[r] */);
 // dx = LN-backward(dy; x, mean, rstd, gamma); out_f32 = dres + dx; out_bf16 = bf16(out_f32)
 // x_stride / o_stride: row pitch (elements) of x and of dres/outputs (D when contiguous);
 // stat_stride: pitch of mean/rstd; dres_T > 0: dres is compact [rows/dres_T][D], non-zero only on
@@ -69,7 +74,7 @@ hipError_t launch_unit_rows(const float* src, int n, int E, int normalize, float
 hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // out[m][n] = (resid ? resid[m][n] : 0) + (bias ? bias[n] : 0) + sum_s part[s][m][n]   (fixed order: deterministic)
 hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr,
-                                const float* bias, float* out, int ldc, hipStream_t s);
+                                const float* bias, float* out, int ldc, hipStream_t s, const int* cmap = nullptr);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 // causal != 0: key j is visible to query i only for j <= i (text tower)
@@ -80,7 +85,7 @@ hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, co
                                 hipStream_t s, int causal = 0);
 // Forward for query 0 of every sequence only (last image-tower layer): writes row n*T of `out` and lse[n][h][0].
 hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
-                                    hipStream_t s);
+                                    hipStream_t s, const int* qpos = nullptr, int causal = 0);
 // Same gradients when d(out) is non-zero only for ONE query of every sequence (the top layer): token 0
 // (CLS) or, with qpos != null, token qpos[sequence] (end-of-text).  dout_cls bf16 [n][H*64]; writes dense
 // dq (zero rows for every other token), dk, dv.
