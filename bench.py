@@ -211,7 +211,7 @@ def main():
         ach1 = gflops1 / (ms1["gemm"] * 1e-3) / 1e12
         # Primary figure: the kernel alone on the chip (one stream).  rocprofv3 --kernel-trace serialises kernels, so
         # its average duration is this regime's whatever --streams is (profiles/: 44.9 us per GEMM launch under both).
-        # With two episodes in flight every launch shares the CUs with the other stream's kernel and takes longer;
+        # With several episodes in flight every launch shares the CUs with the other streams' kernels and takes longer;
         # that regime is reported beside it.
         roof = {"bound": "mfma", "achieved": round(ach1, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per GEMM launch",
