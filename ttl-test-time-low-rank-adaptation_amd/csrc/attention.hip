@@ -594,28 +594,36 @@ hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n,
     return hipGetLastError();
 }
 
+#ifndef TTL_ATTN_NW_DQ
+#define TTL_ATTN_NW_DQ 0
+#endif
+#ifndef TTL_ATTN_NW_DKV
+#define TTL_ATTN_NW_DKV 0
+#endif
 template <int NKT>
 hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
                  op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s, int causal) {
-    // one wave per 32-row block (NKT waves) for the ViT geometries, 4 waves otherwise
-    constexpr int NW = 4;   // (one wave per block, NW = NKT, measured slower here: the dQ pass needs 256 VGPRs)
+    // waves per (sequence, head) block: 0 = one per 32-row block (NKT waves; used), or a fixed count.  In situ on
+    // ViT-B/16 (tools/attn_ab.sh, attention-backward ms per episode): 4/4 waves 0.273, NKT/4 0.229, 8/8 0.222, NKT/NKT 0.205
+    constexpr int NWQ = (TTL_ATTN_NW_DQ == 0) ? NKT : TTL_ATTN_NW_DQ;
+    constexpr int NWK = (TTL_ATTN_NW_DKV == 0) ? NKT : TTL_ATTN_NW_DKV;
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
     constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
     static bool done = false;
     if (!done) {
-        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT, NW>, SMEM_A);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true, NW>, SMEM_B);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false, NW>, SMEM_B);
+        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT, NWQ>, SMEM_A);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true, NWK>, SMEM_B);
+        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false, NWK>, SMEM_B);
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, NW>), dim3(n * H), dim3(64 * NW), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, NWQ>), dim3(n * H), dim3(64 * NWQ), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
                        ldd, T, H, causal);
     if (need_dk)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, true, NWK>), dim3(n * H), dim3(64 * NWK), SMEM_B, s, qkv, ld, out, dout, ldo,
                            lse, dqkv, ldd, T, H, causal);
     else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false, NW>), dim3(n * H), dim3(64 * NW), SMEM_B, s, qkv, ld, out, dout, ldo,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NKT, false, NWK>), dim3(n * H), dim3(64 * NWK), SMEM_B, s, qkv, ld, out, dout, ldo,
                            lse, dqkv, ldd, T, H, causal);
     return hipGetLastError();
 }
