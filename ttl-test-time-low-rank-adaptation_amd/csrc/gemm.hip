@@ -3,7 +3,7 @@
 // Replaces the nn.Linear / Conv2d matmuls the reference runs through torch (HF
 // modeling_clip.py:202-218 patch conv, :309-311 q/k/v, :333 out_proj, :346-350 fc1/fc2) and
 // their autograd dgrad counterparts.  gfx950 design:
-//   * block tile 160 x 128 x 64 (128 x 128 for small M), 4 waves (2x2), two blocks per CU,
+//   * block tile 160 x 128 x 64, 4 waves (2x2), two blocks per CU (32 x 64, 2 waves, 4-stage ring for small M),
 //     v_mfma_f32_16x16x32_bf16, fp32 accumulate
 //   * operands staged HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
 //     stages, next tile's DMA in flight under the current tile's MFMAs
@@ -376,13 +376,20 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
 // 64-71 FLOP per staged byte is near the L2->LDS ceiling: the next step is a larger block tile.
-// Small-M calls (1-view inference, CLS-only top-layer backward) are latency-bound: 128x128 with a
-// 4-stage ring (3 K-tiles of DMA in flight) and the guarded epilogue.
+// Small-M calls (1-view inference, pooled-row GEMMs) are latency-bound: a 4-stage ring (3 K-tiles of DMA in
+// flight), the guarded epilogue and a small tile (see launch_v).
 template <int EPI>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
     static int variant = -1;
     if (variant < 0) { const char* v = getenv("TTL_GEMM_VARIANT"); variant = v ? atoi(v) : 2; }
-    if (a.M < 1024) return (variant == 8) ? launch_t<128, 2, 2, EPI>(a, s) : launch_t<128, 2, 2, EPI, true, 4>(a, s);
+    if (a.M < 1024) {
+        // Small-M calls (1-view inference, pooled-row GEMMs of the last layer and of its backward: M = 64..257) are
+        // latency chains on a handful of blocks, so the tile is SMALL to spread them over more CUs.  In situ, ms of
+        // this class per episode (20 launches, tools/gemm_small_ab.sh): 128x128 4-stage 0.32, 64x128 0.29 (M<=64) /
+        // 0.26 (all), 64x64 0.23, 32x128 0.25, 32x64 0.215 (used; 6 or 8 stages no better), 16x64 / 16x128 0.26.
+        if (variant == 8) return launch_t<128, 2, 2, EPI, true, 4>(a, s);
+        return launch_t<32, 2, 1, EPI, true, 4>(a, s);
+    }
     if (variant == 0) return launch_t<128, 2, 2, EPI>(a, s);
     if (a.padded && EPI != EPI_PATCH) {
         if (variant == 1) return launch_t<320, 4, 2, EPI, false>(a, s);
