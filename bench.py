@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
     ap.add_argument("--streams", type=int, default=3, help="independent episodes in flight per GPU (HIP streams)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="MFMA operand dtype")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay every episode as one HIP graph launch (host-bound small-view runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for smoke-testing the N>1 logic on a 1-GPU box")
@@ -130,7 +131,7 @@ def main():
              for i in range(cfg.layer_lo, cfg.layer_hi + 1) for pj in ("q_proj", "v_proj") for ab in ("A", "B")]
     pipe = EpisodePipeline(cfg, synth.vision_weights(cfg, 0), names, lora,
                            torch.from_numpy(synth.text_features(a.classes, cfg.embed)), 100.0, dev,
-                           n_streams=a.streams, max_views=a.views, precision=a.precision)
+                           n_streams=a.streams, max_views=a.views, precision=a.precision, use_graph=bool(a.graph))
     eng = pipe.slots[0]["eng"]
     # synthetic inputs of the workload's shape, already resident in HBM (data: synthetic)
     pool = [torch.from_numpy(synth.views(cfg, a.views, 1000 + rank * a.pool + j)).to(dev) for j in range(a.pool)]
@@ -193,7 +194,9 @@ def main():
                 with torch.cuda.stream(sl["stream"]):
                     eng.episode(pool[i % a.pool], sl["snap"], sl["m"], sl["v"], n_updates=a.updates)
             sl["stream"].synchronize()
+        graph_mode, pipe.use_graph = pipe.use_graph, False     # per-launch events need real launches, not a graph replay
         ms, cnt, gflops = profiled(run_all, [sl["eng"] for sl in pipe.slots])
+        pipe.use_graph = graph_mode
         alg_bytes = profiled.bytes / max(cnt["gemm"], 1)
         ms1, cnt1, gflops1 = profiled(run_one, [eng])
         # HBM-side traffic of the same launches: PMC passes cannot run inside this process, so the figure is the
@@ -239,7 +242,7 @@ def main():
                                    f"(ImageNet-A shape), layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
                                    f"1-view inference; views pre-staged in HBM; {a.steps} images/rank",
                        "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates,
-                       "streams_per_gpu": a.streams, "parallelism": f"image-sharded x{world}, {a.streams} episodes in flight per GPU"},
+                       "streams_per_gpu": a.streams, "hip_graph": bool(a.graph), "parallelism": f"image-sharded x{world}, {a.streams} episodes in flight per GPU"},
             "tflop_per_image": round(flops / 1e12, 3),
             "whole_path_tflops_per_gpu": round(flops * value / world / 1e12, 1),
             "whole_path_frac_of_bf16_peak": round(flops * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),

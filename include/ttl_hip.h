@@ -161,6 +161,15 @@ typedef struct ttl_episode_args {
 } ttl_episode_args;
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
 
+/* The same episode captured into a HIP graph (stream capture of the launch sequence above) and replayed with one
+ * hipGraphLaunch: the per-image host cost drops from ~130 kernel enqueues to one call.  Every pointer in `args`
+ * (x, snapshot, exp_avg, exp_avg_sq, logits0/1_out) is baked into the graph: keep those buffers alive and refill x
+ * in place.  `stream` must be an explicit stream; ttl_episode_capture also RUNS the episode once (warm-up). */
+typedef struct ttl_graph ttl_graph;
+int ttl_episode_capture(ttl_ctx* ctx, const ttl_episode_args* args, void* stream, ttl_graph** out);
+int ttl_graph_launch(ttl_graph* graph, void* stream);
+void ttl_graph_destroy(ttl_graph* graph);
+
 /* ---- --lora_encoder text (clip/custom_clip.py:602-607,615-616,672-678; ttl.py:143-147,190-192) ----
  * A context created with tower = TTL_TOWER_TEXT holds the HF text tower ("text_model.embeddings.token_embedding.weight",
  * "text_model.embeddings.position_embedding.weight", "text_model.encoder.layers.{i}.*", "text_model.final_layer_norm.*",

@@ -282,3 +282,39 @@ def test_fp16_and_bf16_builds_coexist():
     assert max_rel(b, g["logits0"]) < max_rel(a, g["logits0"])         # fp16 is the more accurate of the two
     assert 1e-5 < max_rel(a, b) < 2e-2                                   # and they really are different builds
     e1.close(); e2.close()
+
+
+def test_episode_as_hip_graph_replays_bit_identically():
+    """ttl_episode_capture / ttl_graph_launch: the captured episode, replayed on new views written into the same
+    buffer, equals the directly enqueued episode bit for bit; the pipeline's use_graph mode agrees too."""
+    from ttl_amd.driver import EpisodePipeline
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0])
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    x0 = torch.from_numpy(x).cuda()
+    x1 = torch.roll(x0, 1, dims=0).contiguous() * 0.9
+    ref0 = eng.episode(x0, snap, m, v, n_updates=1).clone()
+    ref1 = eng.episode(x1, snap, m, v, n_updates=1).clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        xbuf, obuf = x0.clone(), torch.empty_like(ref0)
+        launch = eng.episode_graph(xbuf, snap, m, v, obuf, n_updates=1)
+        s.synchronize()
+        assert torch.equal(obuf, ref0)                      # the capture call runs the episode once
+        xbuf.copy_(x1)
+        out1 = launch().clone()
+        xbuf.copy_(x0)
+        out0 = launch().clone()
+    s.synchronize()
+    assert torch.equal(out1, ref1) and torch.equal(out0, ref0)
+    eng.close()
+    # pipeline with use_graph: same hits and logits as without
+    outs = {}
+    for ug in (False, True):
+        pipe = EpisodePipeline(cfg, W, names, lora0, torch.from_numpy(tf), float(np.exp(W["logit_scale"])), "cuda:0",
+                               n_streams=2, max_views=x.shape[0], use_graph=ug)
+        res = [pipe.submit(xx, target=torch.tensor([3], device="cuda"), n_updates=1) for xx in (x0, x1, x0, x1, x1)]
+        pipe.synchronize()
+        outs[ug] = (torch.stack(res).cpu(), pipe.totals().cpu())
+        pipe.close()
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])

@@ -913,6 +913,47 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     return forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
 }
 
+// ---- the episode as a HIP graph: ~130 launches replayed with one hipGraphLaunch (the enqueue costs the host ~2.7 ms
+// per image otherwise, which bounds small-view-count runs: 8 views take < 1 ms of GPU time)
+struct ttl_graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+
+int ttl_episode_capture(ttl_ctx* c, const ttl_episode_args* a, void* stream, ttl_graph** out) {
+    if (!c || !a || !out) return fail(TTL_EINVAL, "null argument");
+    *out = nullptr;
+    if (c->prof) return fail(TTL_ESTATE, "cannot capture while profiling is enabled (events are recorded per launch)");
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) return fail(TTL_EINVAL, "capture needs an explicit (non-default) stream");
+    // first run outside the capture: one-time hipFuncSetAttribute calls of the launchers must not fall inside it
+    int rc = ttl_episode(c, a, stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = ttl_episode(c, a, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    ttl_graph* tg = new ttl_graph();
+    tg->graph = g;
+    e = hipGraphInstantiate(&tg->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); delete tg; return fail((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    *out = tg;
+    return 0;
+}
+
+int ttl_graph_launch(ttl_graph* g, void* stream) {
+    if (!g || !g->exec) return fail(TTL_EINVAL, "null graph");
+    HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return 0;
+}
+
+void ttl_graph_destroy(ttl_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 // --lora_encoder text (clip/custom_clip.py:672-678): image features of the views without grad on the image-tower
 // context `v` (no adapters bound), then the same update loop on the text-tower context `c`.
 int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* stream) {

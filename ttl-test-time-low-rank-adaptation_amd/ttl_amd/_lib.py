@@ -76,6 +76,9 @@ SIGNATURES = {
     "ttl_text_forward": (_I, [_P, _I, _P, _P, _P]),
     "ttl_text_backward_lora": (_I, [_P, _P, _P]),
     "ttl_episode_text": (_I, [_P, _P, C.POINTER(ttl_episode_args), _P]),
+    "ttl_episode_capture": (_I, [_P, C.POINTER(ttl_episode_args), _P, C.POINTER(_P)]),
+    "ttl_graph_launch": (_I, [_P, _P]),
+    "ttl_graph_destroy": (None, [_P]),
     "ttl_make_views_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "ttl_make_views": (_I, [_P, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _Z, _P]),
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),

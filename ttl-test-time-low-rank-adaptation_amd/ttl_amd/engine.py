@@ -58,6 +58,9 @@ class TTLEngine:
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
+        for g in getattr(self, "_graphs", []):
+            self.lib.ttl_graph_destroy(g)
+        self._graphs = []
         if getattr(self, "_h", None):
             self.lib.ttl_ctx_destroy(self._h)
             self._h = None
@@ -192,6 +195,35 @@ class TTLEngine:
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
         return (l1, l0) if want_logits0 else l1
+
+    def episode_graph(self, x_buf, snapshot, m, v, logits1_buf, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH,
+                      rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        """Capture the episode over FIXED buffers (x_buf [N,3,S,S], logits1_buf [1,K], snapshot / m / v) into a HIP
+        graph on the current (non-default) stream; returns a callable that replays it on the current stream.  The
+        capture itself runs the episode once on whatever x_buf holds."""
+        import math
+        assert x_buf.is_cuda and x_buf.is_contiguous() and logits1_buf.is_contiguous()
+        a = _lib.ttl_episode_args()
+        a.x, a.n_views, a.n_updates = x_buf.data_ptr(), x_buf.shape[0], int(n_updates)
+        a.objective = 0 if objective == "deyo" else 1
+        a.mode, a.rho = int(mode), float(rho)
+        a.thresh = math.log(1000.0) if thresh is None else thresh
+        a.margin, a.reweight = float(margin), float(reweight)
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, betas[0], betas[1], eps, weight_decay
+        a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.logits0_out, a.logits1_out = None, logits1_buf.data_ptr()
+        g = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_episode_capture(self._h, C.byref(a), _stream(), C.byref(g)))
+        self._graphs = getattr(self, "_graphs", [])
+        self._graphs.append(g)
+        keep = (x_buf, snapshot, m, v, logits1_buf)     # the graph holds raw pointers into these
+
+        def launch(_keep=keep):
+            with torch.cuda.device(self.device):
+                self._check(self.lib.ttl_graph_launch(g, _stream()))
+            return logits1_buf
+        return launch
 
     # ------------------------------------------------------------------ debugging / measurement
     def debug_copy(self, name, layer, shape, dtype=np.float32):
