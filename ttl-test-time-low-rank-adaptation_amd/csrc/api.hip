@@ -575,7 +575,9 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
-        if (i == c->L - 1 && (!c->text || n < 1024)) {   // (row maps exist in the small-M GEMM kernels only)
+        static int pooled_last = -1;   // TTL_POOLED_LAST_LAYER=0: run the last layer densely (A/B and the equivalence test)
+        if (pooled_last < 0) { const char* v = getenv("TTL_POOLED_LAST_LAYER"); pooled_last = v ? atoi(v) : 1; }
+        if (pooled_last && i == c->L - 1 && (!c->text || n < 1024)) {   // (row maps exist in the small-M GEMM kernels only)
             // ---- last layer: the head reads ONE row per sequence (image tower: CLS, HF modeling_clip.py pooled =
             // last_hidden_state[:, 0]; text tower: the end-of-text token), so beyond K and V of every token everything
             // runs on those n rows: the query projection, attention for that query, out_proj, LN2 and the MLP — in place,
@@ -756,16 +758,19 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             const op_t* u_rows = l.u; int ld_u = T * F;
             const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
             const float *mu2 = l.mu2, *rs2 = l.rs2;
-            const int stat_pitch = 1;   // the pooled-row forward stores them as [n]
+            static int pooled_last = -1;
+            if (pooled_last < 0) { const char* v = getenv("TTL_POOLED_LAST_LAYER"); pooled_last = v ? atoi(v) : 1; }
+            const bool compact_stats = pooled_last && (!c->text || n < 1024);   // the pooled-row forward stores them as [n]
+            int stat_pitch = compact_stats ? 1 : T;
             if (pool) {
                 Prof p(c, 3, s);
                 HIP_TRY(launch_gather_rows_op(l.u, F, pool, T, c->u_g, n, F, s));
                 HIP_TRY(launch_gather_rows_f32(l.h_mid, D, pool, T, c->hmid_g, n, D, s));
                 u_rows = c->u_g; ld_u = F; hmid_rows = c->hmid_g; hmid_pitch = D;
-                if (n >= 1024) {   // dense last layer (no row maps at this size): statistics sit at every row
+                if (!compact_stats) {   // dense last layer: statistics sit at every row
                     HIP_TRY(launch_gather_rows_f32(l.mu2, 1, pool, T, c->mu2_g, n, 1, s));
                     HIP_TRY(launch_gather_rows_f32(l.rs2, 1, pool, T, c->rs2_g, n, 1, s));
-                    mu2 = c->mu2_g; rs2 = c->rs2_g;
+                    mu2 = c->mu2_g; rs2 = c->rs2_g; stat_pitch = 1;
                 }
             }
             {
