@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void gemm_kernel(const GemmArgs 
 #pragma unroll
             for (int i = NP0; i < NP; ++i) stage_piece(i, kt + 1, nxt);
             mma(xf1, wf1);
-            // Main-loop order, measured IN SITU (tools/gemm_sched_ab.sh + quick_bench.py, GEMM ms per episode):
+            // Main-loop order, measured IN SITU (tools/gemm_macro_ab.sh TTL_GEMM_SCHED 0 1 2 + quick_bench.py, GEMM ms per episode):
             //   0 (used)  DMA pieces spread between the MFMAs ........ 3.52
             //   1         fragments, the DMA as one burst, MFMAs ..... 3.57
             //   2         the compiler's own order ................... 3.70
@@ -386,7 +386,7 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1024) {
         // Small-M calls (1-view inference, pooled-row GEMMs of the last layer and of its backward: M = 64..257) are
         // latency chains on a handful of blocks, so the tile is SMALL to spread them over more CUs.  In situ, ms of
-        // this class per episode (20 launches, tools/gemm_small_ab.sh): 128x128 4-stage 0.32, 64x128 0.29 (M<=64) /
+        // this class per episode (20 launches, tools/gemm_macro_ab.sh): 128x128 4-stage 0.32, 64x128 0.29 (M<=64) /
         // 0.26 (all), 64x64 0.23, 32x128 0.25, 32x64 0.215 (used; 6 or 8 stages no better), 16x64 / 16x128 0.26.
         if (variant == 8) return launch_t<128, 2, 2, EPI, true, 4>(a, s);
         return launch_t<32, 2, 1, EPI, true, 4>(a, s);
