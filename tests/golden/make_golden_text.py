@@ -33,6 +33,7 @@ CASES = {
     "tiny_text_topk": ("tiny", 64, 10, {"filter_ent": 1}),
     "tiny_text_steps2": ("tiny", 8, 10, {"tta_steps": 2}),
     "tiny_text_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
+    "tiny_text_plpd": ("tiny", 64, 10, {"filter_plpd": 1, "plpd_threshold": 0.05}),
     "b16_text_n8_k10": ("ViT-B/16", 8, 10, {}),
     "b16_text_n64_k200": ("ViT-B/16", 64, 200, {}),
 }
@@ -81,6 +82,7 @@ def run_case(case):
     with torch.no_grad():
         model.LoRA_reset()
     opt.load_state_dict(opt_state)
+    torch.manual_seed(4321)        # the PLPD patch permutation draws torch.rand from the CPU generator
     ttl.test_time_tuning(model, x, opt, scaler, args)
     grads = {k: (p.grad.detach().clone().numpy() if p.grad is not None else None) for k, p in lora_named(model).items()}
     lora1 = {k: v.detach().clone().numpy() for k, v in lora_named(model).items()}
@@ -102,7 +104,21 @@ def run_case(case):
         coeff = args.reweight_ent * (1 / torch.exp(e.clone().detach() - args.deyo_margin_e0))
         loss = e.mul(coeff).mean(0)
     n_updates = args.tta_steps ** 2 if args.deyo_selection else args.tta_steps
-    assert len(rec["logits"]) == n_updates + 1
+    extra = {}
+    if args.filter_plpd:           # second stage of the update, through the reference's formulae (deyo.py:137-151)
+        assert len(rec["logits"]) == 2 * n_updates + 1
+        zp = rec["logits"][1]
+        prob, prob_p = z0[idx].softmax(1), zp.softmax(1)
+        cls1 = prob.argmax(dim=1)
+        plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_p, 1, cls1.reshape(-1, 1))).reshape(-1)
+        ids2 = torch.where(plpd > args.plpd_threshold)[0]
+        e2 = Hs[idx][ids2]
+        coeff = args.reweight_ent * (1 / torch.exp(e2.clone().detach() - args.deyo_margin_e0))
+        loss = e2.mul(coeff).mean(0)
+        extra = dict(plpd=plpd.numpy(), idx2=idx[ids2].numpy().astype(np.int64), logits_prime=zp.numpy(),
+                     plpd_threshold=args.plpd_threshold, patch_len=args.patch_len, rng_seed=4321)
+    else:
+        assert len(rec["logits"]) == n_updates + 1
     with torch.no_grad():
         fimg = model.image_encoder(x)
         fimg = fimg / fimg.norm(dim=-1, keepdim=True)
@@ -115,8 +131,9 @@ def run_case(case):
                margin=args.deyo_margin_e0, n_updates=n_updates, lr=args.lr,
                image_features=fimg.numpy(), text_features_after=model.text_features.detach().numpy(),
                logits0=z0.numpy(), H=Hs.numpy(), idx=idx.numpy().astype(np.int64), coeff=coeff.numpy(),
-               loss=np.float32(loss.item()), logits_last=rec["logits"][n_updates - 1].numpy(),
+               loss=np.float32(loss.item()), logits_last=rec["logits"][(2 if args.filter_plpd else 1) * n_updates - (2 if args.filter_plpd else 1)].numpy(),
                logits1=out1.numpy(), top5=torch.topk(out1, min(5, K), dim=1).indices.numpy())
+    out.update(extra)
     for k in (lora0 if cfg.width <= 128 else trained):
         out["lora0/" + k] = lora0[k]
     for k in trained:

@@ -274,3 +274,24 @@ def test_eval_loop_text_mode():
         model.LoRA_reset()
     top1, top5 = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=2)
     assert abs(top1 - 100.0 * hits[0].item() / 4) < 1e-9 and abs(top5 - 100.0 * hits[1].item() / 4) < 1e-9
+
+
+def test_plpd_filter_text_mode_matches_reference():
+    """--filter_plpd 1 with --lora_encoder text (deyo.py:115-151): same destroyed views, same surviving set, same counts
+    as the reference's fixture; the PLPD forward reuses the pending forward's text features."""
+    from ttl_amd import deyo as D
+    g, tcfg, model, opt, opt_state, x = build_model("tiny_text_plpd")
+    model.precision = "fp16"          # PLPD thresholds a probability difference: use the tighter build
+    args = text_args(filter_plpd=1, plpd_threshold=float(g["plpd_threshold"]), aug_type="patch", patch_len=int(g["patch_len"]))
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    torch.manual_seed(int(g["rng_seed"]))
+    d = D.DeYO(model, args, opt, None, steps=1, deyo_margin=args.deyo_margin, margin_e0=args.deyo_margin_e0)
+    outputs, backward, final_backward = d(x)
+    assert backward == len(g["idx"]) and final_backward == len(g["idx2"])
+    assert max_rel(outputs.cpu().numpy(), g["logits0"]) < 5e-3
+    with torch.no_grad():
+        out = model(x[:1])
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 3e-2
+    assert int(out.argmax()) == int(g["top5"][0, 0])

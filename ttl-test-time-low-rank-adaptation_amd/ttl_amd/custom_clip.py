@@ -111,7 +111,19 @@ class _TextModeEngine:
 
     def forward(self, x, save=False, want_features=False):
         self.txt.set_image_features(self.img.features(x), normalize=True)
-        return self.txt.forward(save=save, want_features=want_features)
+        out = self.txt.forward(save=save, want_features=True)
+        self._last_text = out[1]                 # un-normalised text features of this forward (PLPD reuses them)
+        return out if want_features else out[0]
+
+    def logits_same_text(self, x):
+        """Logits of other views against the text features of the LAST forward, without touching the text context
+        (whose saved activations and image features belong to a pending backward): the PLPD forward of deyo.py:135.
+        The adapters have not changed in between, so the reference's recomputed text features are the same ones.
+        A [n,E] x [E,K] product in torch: host-side glue, like the reference's own softmax / gather around it."""
+        f = self.img.features(x)
+        f = f / f.norm(dim=-1, keepdim=True)
+        t = self._last_text / self._last_text.norm(dim=-1, keepdim=True)
+        return self.txt._scale * f @ t.t()
 
     def backward(self, dlogits):
         return self.txt.backward(dlogits)
@@ -137,6 +149,17 @@ class _TextModeEngine:
     def close(self):
         self.img.close()
         self.txt.close()
+
+
+class _PlpdTextForward:
+    """What deyo.forward_and_adapt_sar needs from the auxiliary context, for lora_encoder == 'text'."""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def forward(self, x, save=False):
+        assert not save
+        return self.eng.logits_same_text(x)
 
 
 def build_text_mode_engine(vcfg, tcfg, vision_state, text_state, prompts, logit_scale_exp, device, max_views, max_prompts,
@@ -430,7 +453,7 @@ class ClipTestTimeTuning(nn.Module):
         (the PLPD forward of deyo.py:135 sits between model(x) and loss.backward()).  Shares the LoRA
         parameter buffer, so it always sees the current adapter weights."""
         if self.lora_encoder == 'text':
-            raise NotImplementedError("--filter_plpd with --lora_encoder text is not built")
+            return _PlpdTextForward(self._ensure_engine())
         self._ensure_engine()
         aux = getattr(self, "_aux", None)
         if aux is None or aux.device != self.engine.device or aux.n_classes != self.engine.n_classes \
