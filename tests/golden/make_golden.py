@@ -38,6 +38,9 @@ CASES = {
     "tiny_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
     "tiny197_deyo": ("tiny197", 8, 10, {}),
     "tiny_plpd": ("tiny", 64, 10, {"filter_plpd": 1, "plpd_threshold": 0.17}),
+    "tiny_plpd_occ": ("tiny", 64, 10, {"filter_plpd": 1, "aug_type": "occ", "occlusion_size": 24, "row_start": 16,
+                                       "column_start": 20, "plpd_threshold": -0.026}),
+    "tiny_plpd_pixel": ("tiny", 64, 10, {"filter_plpd": 1, "aug_type": "pixel", "plpd_threshold": -0.129}),
     "b16_n8_k10": ("ViT-B/16", 8, 10, {}),
     "b16_n64_k200_ent0": ("ViT-B/16", 64, 200, {}),
     "b16_n64_k200_ent1": ("ViT-B/16", 64, 200, {"filter_ent": 1}),
@@ -112,7 +115,7 @@ def run_case(case):
     hook = model.register_forward_hook(lambda m, i, o: rec["logits"].append(o.detach().clone()))
     taps = {}
     hooks = []
-    if cfg.width <= 128:
+    if cfg.width <= 128 and "plpd_" not in case:      # (the extra PLPD variants only need the step-level records)
         vm = model.image_encoder.vision_model
         first = {"done": False}
 
@@ -170,7 +173,8 @@ def run_case(case):
         coeff = args.reweight_ent * (1 / torch.exp(e2.clone().detach() - args.deyo_margin_e0))
         loss = e2.mul(coeff).mean(0)
         extra = dict(plpd=plpd.numpy(), idx2=idx[ids2].numpy().astype(np.int64), logits_prime=zp.numpy(),
-                     plpd_threshold=args.plpd_threshold, patch_len=args.patch_len, rng_seed=4321)
+                     plpd_threshold=args.plpd_threshold, patch_len=args.patch_len, rng_seed=4321, aug_type=args.aug_type,
+                     occlusion_size=args.occlusion_size, row_start=args.row_start, column_start=args.column_start)
     else:
         extra = {}
     trained = [k for k in lora0 if any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1))]

@@ -179,15 +179,20 @@ def test_eval_loop_matches_per_image_surface():
     assert abs((parts[0][0] + parts[1][0]) / 2 - top1) < 1e-9
 
 
-def test_plpd_filter_matches_reference():
-    """--filter_plpd 1 (deyo.py:115-151) through this build's test_time_tuning: same destroyed views (the patch
-    permutation comes from torch's CPU generator, seeded like the fixture), same surviving set, same counts."""
+@pytest.mark.parametrize("name", ["tiny_plpd", "tiny_plpd_occ", "tiny_plpd_pixel"])
+def test_plpd_filter_matches_reference(name):
+    """--filter_plpd 1 (deyo.py:115-151) through this build's test_time_tuning, all three --aug_type variants: same
+    destroyed views (patch / pixel permutations come from torch's CPU generator, seeded like the fixture; 'occ' fills a
+    window with the view mean), same surviving set, same counts."""
     import torch.nn.functional as F  # noqa: F401
     from ttl_amd.ttl import test_time_tuning
     from ttl_amd import deyo as D
-    g, cfg, model, opt, opt_state, x = build("tiny_plpd")
+    g, cfg, model, opt, opt_state, x = build(name)
     model.precision = "fp16"          # PLPD thresholds a probability difference: use the tighter build
-    args = ref_args(filter_plpd=1, plpd_threshold=float(g["plpd_threshold"]), aug_type="patch", patch_len=int(g["patch_len"]))
+    aug = str(g["aug_type"]) if "aug_type" in g.files else "patch"
+    args = ref_args(filter_plpd=1, plpd_threshold=float(g["plpd_threshold"]), aug_type=aug, patch_len=int(g["patch_len"]))
+    if aug == "occ":
+        args.occlusion_size, args.row_start, args.column_start = int(g["occlusion_size"]), int(g["row_start"]), int(g["column_start"])
     with torch.no_grad():
         model.LoRA_reset()
     opt.load_state_dict(opt_state)
