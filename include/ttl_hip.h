@@ -44,7 +44,8 @@ typedef struct ttl_config {
     int rank;         /* r: 16 or 32 */
     float lora_alpha; /* 32 */
     int layer_lo;     /* first encoder layer whose q/v adapters train */
-    int layer_hi;     /* last one (inclusive) */
+    int layer_hi;     /* last one (inclusive); may be below the top layer: the layers above it then carry no
+                       * trainable adapters but still pass the gradient down (their activations are saved too) */
     float ln_eps;     /* 1e-5 */
     int max_views;    /* capacity N of one ttl_vit_forward call (text tower: capacity in prompts) */
     int max_classes;  /* capacity K (text tower: capacity in image views) */

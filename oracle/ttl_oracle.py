@@ -279,7 +279,7 @@ class VitOracle:
         u = (x2 @ r(self._lw(i, "mlp.fc1.weight")).T + self._lw(i, "mlp.fc1.bias")).astype(np.float32)
         g = r(quick_gelu(u).astype(np.float32))
         ho = (hm + g @ r(self._lw(i, "mlp.fc2.weight")).T + self._lw(i, "mlp.fc2.bias")).astype(np.float32)
-        if save is not None and self.trained(i):
+        if save is not None and i >= c.layer_lo:     # every layer the gradient passes through, adapters or not
             save[i] = dict(h_in=h, mu1=mu1, rs1=rs1, x1=x1, U=U, q=q, k=k, v=v,
                            lse=(mx + np.log(den))[..., 0], o=o, h_mid=hm, mu2=mu2, rs2=rs2,
                            u=r(u))
@@ -342,7 +342,9 @@ class VitOracle:
         T, D, Hh, dhd = c.tokens, c.width, c.heads, c.head_dim
         s = np.float32(c.scaling)
         grads = {}
-        for i in range(c.layer_hi, c.layer_lo - 1, -1):
+        # from the LAST layer down to layer_lo: layers above layer_hi are frozen (no adapters trained, B == 0 forever,
+        # Q10) but lie on the path from the loss to the adapters below them (--layer_range need not end at the top)
+        for i in range(c.layers - 1, c.layer_lo - 1, -1):
             sv = save[i]
             first = (i == c.layer_lo)
             # MLP
@@ -370,6 +372,8 @@ class VitOracle:
             base = f"{self.tower}.encoder.layers.{i}.self_attn."
             dU = {}
             for pj, dproj in (("q_proj", dq), ("v_proj", dv)):
+                if not self.trained(i):
+                    continue
                 A, B = self._lora(i, pj, "A"), self._lora(i, pj, "B")
                 Us = sv["U"][pj].reshape(N * T, -1)            # = s·x1·A^T
                 grads[base + pj + ".lora_B.default.weight"] = (dproj.T @ Us).astype(np.float32)
@@ -381,9 +385,10 @@ class VitOracle:
             dk = merge(dK)
             dx1 = (dq @ r(self._lw(i, "self_attn.q_proj.weight"))
                    + dk @ r(self._lw(i, "self_attn.k_proj.weight"))
-                   + dv @ r(self._lw(i, "self_attn.v_proj.weight"))
-                   + dU["q_proj"] @ r(self._lora(i, "q_proj", "A"))
-                   + dU["v_proj"] @ r(self._lora(i, "v_proj", "A"))).reshape(N, T, D)
+                   + dv @ r(self._lw(i, "self_attn.v_proj.weight")))
+            if self.trained(i):
+                dx1 = dx1 + dU["q_proj"] @ r(self._lora(i, "q_proj", "A")) + dU["v_proj"] @ r(self._lora(i, "v_proj", "A"))
+            dx1 = dx1.reshape(N, T, D)
             dh = dhm + layer_norm_bwd(dx1, sv["h_in"], sv["mu1"], sv["rs1"], self._lw(i, "layer_norm1.weight"))
         return grads
 

@@ -38,6 +38,8 @@ CASES = {
     "tiny_tpt": ("tiny", 64, 10, {"deyo_selection": False, "tta_steps": 2}),
     "tiny197_deyo": ("tiny197", 8, 10, {}),
     "tiny_plpd": ("tiny", 64, 10, {"filter_plpd": 1, "plpd_threshold": 0.17}),
+    "tiny_mid_deyo": ("tiny_mid", 8, 10, {}),
+    "tiny_all_deyo": ("tiny_all", 8, 10, {}),
     "tiny_plpd_occ": ("tiny", 64, 10, {"filter_plpd": 1, "aug_type": "occ", "occlusion_size": 24, "row_start": 16,
                                        "column_start": 20, "plpd_threshold": -0.026}),
     "tiny_plpd_pixel": ("tiny", 64, 10, {"filter_plpd": 1, "aug_type": "pixel", "plpd_threshold": -0.129}),

@@ -34,8 +34,13 @@ def test_config_validation_without_gpu():
     assert b"width" in lib.ttl_last_error()
     ok = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 9, 11, 1e-5, 64, 1000)
     assert lib.ttl_workspace_bytes(C.byref(ok)) > 500e6
-    mid = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 3, 5, 1e-5, 64, 1000)    # layer_hi must be last
-    assert lib.ttl_workspace_bytes(C.byref(mid)) == 0
+    # --layer_range need not end at the top layer: layers 6..11 then keep their activations for the backward
+    mid = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 3, 5, 1e-5, 64, 1000)
+    assert lib.ttl_workspace_bytes(C.byref(mid)) > lib.ttl_workspace_bytes(C.byref(ok))
+    inv = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 7, 5, 1e-5, 64, 1000)    # lo > hi
+    assert lib.ttl_workspace_bytes(C.byref(inv)) == 0 and b"layer range" in lib.ttl_last_error()
+    inv2 = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 9, 12, 1e-5, 64, 1000)   # hi beyond the tower
+    assert lib.ttl_workspace_bytes(C.byref(inv2)) == 0
 
 
 def test_no_cpu_fallback():

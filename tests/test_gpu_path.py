@@ -10,7 +10,7 @@ from helpers import load_case, episode_kwargs, max_rel, check_lora_step, adamw_f
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo"]
+CASES = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo", "tiny_mid_deyo", "tiny_all_deyo"]
 
 
 def make_engine(cfg, W, lora0, tf, n_views, precision="bf16"):

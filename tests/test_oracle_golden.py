@@ -6,7 +6,7 @@ import pytest
 from oracle import ttl_oracle as O
 from helpers import load_case, episode_kwargs, max_rel, check_lora_step
 
-TINY = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo"]
+TINY = ["tiny_deyo", "tiny_topk", "tiny_steps2", "tiny_r32", "tiny_tpt", "tiny197_deyo", "tiny_mid_deyo", "tiny_all_deyo"]
 
 
 @pytest.fixture(scope="module")

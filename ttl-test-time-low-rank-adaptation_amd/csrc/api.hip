@@ -62,7 +62,9 @@ struct Layer {
     float* h_in; float* h_mid;
     op_t* x1ext; op_t* qkv; op_t* attn; op_t* u;
     float* lse; float *mu1, *rs1, *mu2, *rs2;
-    bool trained;
+    bool trained;     // i >= layer_lo: activations saved, dgrad images kept, gradient flows through it
+    bool lora;        // layer_lo <= i <= layer_hi: carries trainable adapters (--layer_range); layers above layer_hi are
+                      // frozen in the reference (B == 0 forever, Q10) but still lie on the gradient's path
     unsigned loaded;  // bitmask of loaded tensors
 };
 
@@ -70,7 +72,7 @@ struct Layer {
 
 struct ttl_ctx {
     ttl_config c;
-    int D, F, H, T, E, L, P, S, G2, r, Kp, ldx, ldw, ldwt, nT;  // nT: trained layers
+    int D, F, H, T, E, L, P, S, G2, r, Kp, ldx, ldw, ldwt, nT, nS;  // nT: layers with adapters, nS: saved layers (layer_lo..L-1)
     int Mmax;
     float scaling;
     std::vector<void*> allocs;
@@ -95,7 +97,7 @@ struct ttl_ctx {
     float* lora_p = nullptr; float* lora_g = nullptr; size_t lora_n = 0;
     // shared activations
     op_t* patches; float* h;  // running residual stream
-    float* h_out[8];             // outputs of trained layers (h_out[i] = input of the next one)
+    std::vector<float*> h_out;   // outputs of the saved layers (h_out[i] = input of the next one)
     op_t *x1, *qkv, *attn, *x2, *g;
     float *cls_mean, *cls_rstd, *ycls, *feat, *logits, *dlogits, *head_te, *head_td;
     // backward scratch
@@ -146,10 +148,8 @@ int check_config(const ttl_config* k) {
         if (k->context_length < 2 || k->context_length > 128 || k->vocab_size < 2)
             return fail(TTL_EINVAL, "bad context_length %d / vocab_size %d", k->context_length, k->vocab_size);
     } else if (k->patch_size < 1 || k->image_size % k->patch_size || k->image_size % 8) return fail(TTL_EINVAL, "bad image/patch size");
-    if (k->layer_lo < 0 || k->layer_hi >= k->layers || k->layer_lo > k->layer_hi || k->layer_hi - k->layer_lo >= 8)
-        return fail(TTL_EINVAL, "bad layer range [%d,%d]", k->layer_lo, k->layer_hi);
-    if (k->layer_hi != k->layers - 1)
-        return fail(TTL_EINVAL, "layer_hi must be the last encoder layer (%d); got %d", k->layers - 1, k->layer_hi);
+    if (k->layer_lo < 0 || k->layer_hi >= k->layers || k->layer_lo > k->layer_hi)
+        return fail(TTL_EINVAL, "bad layer range [%d,%d] for %d layers", k->layer_lo, k->layer_hi, k->layers);
     int T = k->tower == TTL_TOWER_TEXT ? k->context_length : (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
     if (T > 288) return fail(TTL_EINVAL, "token count %d > 288 unsupported", T);
     if (k->max_views < 1 || k->max_classes < 1 || k->embed < 1 || k->embed > 4096) return fail(TTL_EINVAL, "bad capacities");
@@ -167,6 +167,7 @@ void set_geometry(ttl_ctx* c, const ttl_config* k) {
     c->ldw = c->D + 64;        // wqkv rows
     c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
     c->nT = k->layer_hi - k->layer_lo + 1;
+    c->nS = k->layers - k->layer_lo;
     c->Mmax = round_up(k->max_views * c->T, 1280);  // padded: the big GEMM tiles store whole row tiles unguarded
     c->scaling = k->lora_alpha / (float)k->rank;
 }
@@ -218,7 +219,7 @@ const char* ttl_operand_dtype(void) { return TTL_OPERAND_NAME; }
 size_t ttl_workspace_bytes(const ttl_config* k) {
     if (check_config(k)) return 0;
     ttl_ctx t; set_geometry(&t, k);
-    size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nT, N = k->max_views;
+    size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nS, N = k->max_views;   // (saved layers: layer_lo..L-1)
     size_t w = L * (3 * D * t.ldw + D * D + 2 * D * F) * 2 + nT * (D * t.ldwt + D * D + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
                (t.text ? (size_t)k->vocab_size * D * 4 : 0);
     size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * D + M * F) * 2 +
@@ -243,7 +244,8 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     for (int i = 0; i < c->L; ++i) {
         Layer& l = c->layers[i];
         memset(&l, 0, sizeof l);
-        l.trained = (i >= k->layer_lo && i <= k->layer_hi);
+        l.trained = (i >= k->layer_lo);
+        l.lora = (i >= k->layer_lo && i <= k->layer_hi);
         ALLOC(l.wqkv, 3 * D * c->ldw, true); ALLOC(l.bqkv, 3 * D, true);
         ALLOC(l.wo, D * D, false); ALLOC(l.bo, D, true);
         ALLOC(l.w1, F * D, false); ALLOC(l.b1, F, true);
@@ -273,7 +275,8 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->tfeat, (size_t)k->max_classes * E, true); ALLOC(c->tfeatT, (size_t)k->max_classes * E, true);
     ALLOC(c->patches, N * c->G2 * c->Kp, true);
     ALLOC(c->h, M * D, false);
-    for (int i = 0; i < c->nT; ++i) ALLOC(c->h_out[i], M * D, false);
+    c->h_out.assign(c->nS, nullptr);
+    for (int i = 0; i < c->nS; ++i) ALLOC(c->h_out[i], M * D, false);
     ALLOC(c->x1, M * D, false); ALLOC(c->qkv, M * 3 * D, false); ALLOC(c->attn, M * D, false);
     ALLOC(c->x2, M * D, false); ALLOC(c->g, M * F, false);
     ALLOC(c->cls_mean, N, false); ALLOC(c->cls_rstd, N, false); ALLOC(c->ycls, N * D, false); ALLOC(c->feat, N * E, false);
@@ -559,8 +562,9 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     }
     for (int i = from_layer; i < c->L; ++i) {
         Layer& l = c->layers[i];
-        const bool tr = l.trained && c->lora_p;   // LoRA path active (B == 0 forever in the other layers, Q10; no adapters
-                                                  // at all on the image tower when the text tower is the one being tuned)
+        const bool tr = l.trained && c->lora_p;   // on the gradient's path: activations kept in their own buffers (no
+                                                  // adapters at all on the image tower when the text tower is the one being tuned)
+        const bool lo = tr && l.lora;             // LoRA path active (B == 0 forever in the other layers, Q10)
         const bool sv = tr && save;
         op_t* x1 = tr ? l.x1ext : c->x1;
         const int ldx1 = tr ? c->ldx : D;
@@ -571,7 +575,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             Prof p(c, 3, s);
             HIP_TRY(launch_layernorm(h_in, D, l.ln1g, l.ln1b, nullptr, x1, ldx1, sv ? l.mu1 : nullptr, sv ? l.rs1 : nullptr, M, D, c->c.ln_eps, s));
         }
-        if (tr) {
+        if (lo) {
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
@@ -586,7 +590,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             // 155 of the 2263 GFLOP of a 64-view image forward disappear.
             const int* map = c->text ? c->poolrows : nullptr;
             const long long pitch = map ? 1 : T;                  // row pitch multiplier when addressing by stride
-            const int Kq = tr ? D + 64 : D;
+            const int Kq = lo ? D + 64 : D;
             {
                 GemmArgs a = {};   // K and V for all tokens: rows D..3D of the [3D][ldw] weight image
                 a.A = x1; a.lda = ldx1; a.B = l.wqkv + (size_t)D * c->ldw; a.ldb = c->ldw; a.M = M; a.N = 2 * D; a.K = Kq;
@@ -634,7 +638,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         }
         {
             GemmArgs a = {};
-            a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = tr ? D + 64 : D;
+            a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = lo ? D + 64 : D;
             a.C = qkv; a.ldc = 3 * D; a.bias = l.bqkv;
             if ((rc = gemm(c, EPI_OP, a, s))) return rc;
         }
@@ -741,15 +745,15 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
     float* dh_alt = c->dh2;
     {
         Prof p(c, 5, s);
-        HeadArgs a = head_args(c, c->h_out[c->nT - 1], nullptr, c->logits);
+        HeadArgs a = head_args(c, c->h_out[c->nS - 1], nullptr, c->logits);
         HIP_TRY(launch_head_bwd(a, dlogits, c->dcls, c->dcls16, n, s));
     }
     const size_t per = (size_t)r * D;
     const float* dres_cls = nullptr;   // != null: d/d h_mid of the layer above is compact (CLS rows only)
-    for (int i = c->c.layer_hi; i >= c->c.layer_lo; --i) {
+    for (int i = c->L - 1; i >= c->c.layer_lo; --i) {
         Layer& l = c->layers[i];
         const bool first = (i == c->c.layer_lo);
-        if (i == c->c.layer_hi) {
+        if (i == c->L - 1) {
             // ---- top layer: the loss reads the CLS token only, so d/d h_out is non-zero on the n CLS
             // rows: MLP, LN2 and out_proj backward run on a compact [n, .] problem (row pitch T*D / T*F
             // picks the CLS rows of the saved activations) and attention backward is rank-1 per head.
@@ -834,8 +838,8 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             dres_cls = nullptr;
         }
         float* dhm = dh_alt;  // d/d h_mid (dense layers)
-        // ---- LoRA: dU = s·[dq·B_q | dv·B_v] ; dA, dB
-        {
+        // ---- LoRA: dU = s·[dq·B_q | dv·B_v] ; dA, dB   (layers above layer_hi carry no trainable adapters)
+        if (l.lora) {
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(c->dqkv, c->ldwt, 0, 2 * D, l.btcat, D, r, c->scaling, c->dqkv + 3 * D, c->ldwt, M, s));
             float* g = c->lora_g + (size_t)(i - c->c.layer_lo) * 4 * per;
@@ -845,7 +849,7 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
         // ---- dx1 = [dq dk dv | dU]·[Wqkv | A]  ; dh_in = dh_mid + LN1^T(dx1)
         {
             GemmArgs a = {};
-            a.A = c->dqkv; a.lda = c->ldwt; a.B = l.wqkvT; a.ldb = c->ldwt; a.M = M; a.N = D; a.K = c->ldwt;
+            a.A = c->dqkv; a.lda = c->ldwt; a.B = l.wqkvT; a.ldb = c->ldwt; a.M = M; a.N = D; a.K = l.lora ? c->ldwt : 3 * D;
             a.C = c->dx; a.ldc = D;
             if ((rc = gemm(c, EPI_F32, a, s))) return rc;
         }

@@ -95,13 +95,17 @@ VIT_L14 = VitConfig(name="ViT-L/14", patch_size=14, width=1024, heads=16, mlp=40
 VIT_TINY = VitConfig(name="tiny", image_size=64, patch_size=16, width=128, heads=2, mlp=512,
                      layers=4, embed=64, layer_lo=1, layer_hi=3)
 VIT_TINY197 = VIT_TINY.replace(name="tiny197", image_size=224)
+VIT_TINY_MID = VIT_TINY.replace(name="tiny_mid", layer_lo=1, layer_hi=2)    # --layer_range that stops below the top layer
+VIT_TINY_ALL = VIT_TINY.replace(name="tiny_all", layer_lo=0, layer_hi=3)    # every layer trained (get_coop's own default)
 
 TEXT_B16 = TextConfig()
 TEXT_L14 = TextConfig(name="ViT-L/14-text", width=768, heads=12, mlp=3072, embed=768)
 TEXT_TINY = TextConfig(name="tiny-text", width=128, heads=2, mlp=512, layers=4, embed=64, layer_lo=1, layer_hi=3)
-TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-L/14": TEXT_L14, "tiny": TEXT_TINY, "tiny197": TEXT_TINY}
+TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-L/14": TEXT_L14, "tiny": TEXT_TINY, "tiny197": TEXT_TINY, "tiny_mid": TEXT_TINY,
+              "tiny_all": TEXT_TINY}
 
-ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197}
+ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197, "tiny_mid": VIT_TINY_MID,
+         "tiny_all": VIT_TINY_ALL}
 
 
 def get_config(arch: str) -> VitConfig:
