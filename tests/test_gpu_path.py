@@ -176,13 +176,14 @@ def test_vit_b16_against_reference_goldens(name):
     eng.close()
 
 
-def test_vit_l14_forward_and_step_vs_oracle():
+@pytest.mark.parametrize("arch", ["ViT-L/14", "ViT-B/32"])
+def test_other_geometries_forward_and_step_vs_oracle(arch):
     """BASELINE config 4 geometry (ViT-L/14: D=1024, 24 layers, P=14, T=257, E=768; LoRA on layers
-    21-23).  The reference cannot run it (its HF weights are hard-coded to B/16), so the
-    checker is the bf16-emulating oracle on 2 views."""
+    21-23) and ViT-B/32 (P=32, T=50).  The reference cannot run them (its HF weights are hard-coded to
+    B/16), so the checker is the bf16-emulating oracle on 2 views."""
     from ttl_amd import synth
     from ttl_amd.config import get_config
-    cfg = get_config("ViT-L/14")
+    cfg = get_config(arch)
     W = synth.vision_weights(cfg, 0)
     lora0 = synth.lora_init(cfg, 0)
     x = synth.views(cfg, 2, 5)

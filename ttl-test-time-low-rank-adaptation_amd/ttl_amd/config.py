@@ -89,6 +89,7 @@ class TextConfig:
 
 
 VIT_B16 = VitConfig()
+VIT_B32 = VitConfig(name="ViT-B/32", patch_size=32)            # the run script's other ARCH option (scripts/test_ttl.sh:7)
 VIT_L14 = VitConfig(name="ViT-L/14", patch_size=14, width=1024, heads=16, mlp=4096,
                     layers=24, embed=768, layer_lo=21, layer_hi=23)
 # reduced geometries used by the parity fixtures (tests/golden/make_golden.py)
@@ -101,10 +102,10 @@ VIT_TINY_ALL = VIT_TINY.replace(name="tiny_all", layer_lo=0, layer_hi=3)    # ev
 TEXT_B16 = TextConfig()
 TEXT_L14 = TextConfig(name="ViT-L/14-text", width=768, heads=12, mlp=3072, embed=768)
 TEXT_TINY = TextConfig(name="tiny-text", width=128, heads=2, mlp=512, layers=4, embed=64, layer_lo=1, layer_hi=3)
-TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-L/14": TEXT_L14, "tiny": TEXT_TINY, "tiny197": TEXT_TINY, "tiny_mid": TEXT_TINY,
+TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-B/32": TEXT_B16, "ViT-L/14": TEXT_L14, "tiny": TEXT_TINY, "tiny197": TEXT_TINY, "tiny_mid": TEXT_TINY,
               "tiny_all": TEXT_TINY}
 
-ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197, "tiny_mid": VIT_TINY_MID,
+ARCHS = {"ViT-B/16": VIT_B16, "ViT-B/32": VIT_B32, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197, "tiny_mid": VIT_TINY_MID,
          "tiny_all": VIT_TINY_ALL}
 
 
