@@ -345,7 +345,11 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
         // columns of the XCD grid: halve the weight slice until it sits comfortably in a 4 MiB L2
         const size_t limit = (size_t)xcd2d * 1536 * 1024;
         int xc = 1;
-        while (xc < 8 && (size_t)a.N * a.K * sizeof(op_t) / xc > limit && ntn % (2 * xc) == 0) xc *= 2;
+        // Only wide outputs (N >= 1536): at N = 768 the six column tiles of a row panel already run side by side on one
+        // XCD, and splitting them makes two XCDs fetch the (long-K) activation panel.  HBM-side read bytes per launch
+        // (rocprofv3 FETCH_SIZE): QKV 96 -> 75 MB, fc1 179 -> 118, MLP dgrad 257 -> 196 with the split; out_proj / fc2
+        // 111 -> 140 and the dX GEMMs 102 -> 154 if it were applied to them too.
+        while (a.N >= 1536 && xc < 8 && (size_t)a.N * a.K * sizeof(op_t) / xc > limit && ntn % (2 * xc) == 0) xc *= 2;
         const int xr_n = 8 / xc;
         b.xc = xc;
         nblk = 8 * ((ntm + xr_n - 1) / xr_n) * (ntn / xc);
