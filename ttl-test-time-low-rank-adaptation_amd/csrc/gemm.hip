@@ -50,6 +50,12 @@ struct SchedLoop<NP, NP, NP0, MPER, DPER> {
 #ifndef TTL_GEMM_NT_STORE
 #define TTL_GEMM_NT_STORE 0
 #endif
+// Exception (TTL_GEMM_NT_GELU: 1 = g, 2 = g and u; 2 used): fc1's outputs, 77-155 MB per launch.  g is consumed once by
+// fc2, u only by the backward; storing them non-temporally cuts the launch's HBM-side traffic (all big-M GEMMs: 158 ->
+// 149 MB per launch) and is +0.8 % images/s with one and with three episodes in flight.
+#ifndef TTL_GEMM_NT_GELU
+#define TTL_GEMM_NT_GELU 2
+#endif
 template <typename V>
 __device__ __forceinline__ void st_out(V* p, V v) {
 #if TTL_GEMM_NT_STORE
@@ -94,7 +100,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                 st_out((f32x4*)((float*)a.C + orow * a.ldc + n0), f32x4{v0, v1, v2, v3});
             } else {
                 if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) st_out((u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+                    if (a.C2) {
+                        if (TTL_GEMM_NT_GELU == 2) __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0));
+                        else st_out((u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+                    }
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                 }
                 if constexpr (EPI == EPI_GELU_BWD) {
@@ -102,6 +111,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                     v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
                     v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
                 }
+                if (TTL_GEMM_NT_GELU && EPI == EPI_GELU)
+                    __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)((op_t*)a.C + (size_t)pc * a.ldc + n0));
+                else
                 st_out((u32x2*)((op_t*)a.C + (size_t)pc * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
             }
         }
