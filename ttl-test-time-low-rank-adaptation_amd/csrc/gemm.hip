@@ -389,6 +389,8 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 //   side, 160 x 32 each; two K-tiles in flight per block instead of one; bit-identical results): 4.32 ms vs 3.47
 //   in situ.  A register-destination B load touches 16 lines x 64 B per instruction (half lines, twice the
 //   line requests of the DMA), and the 2-column-per-lane epilogue halves the store width.
+//   cache-policy bits on the operand DMA (global_load_lds aux): sc0 on A neutral, nt on A -16 % (the panel IS re-read
+//   by the other column tiles); non-temporal residual loads in the epilogue -2 %.
 // M = 12608 gives 79 row tiles, so N = 768 / 2304 / 3072 launch 474 / 1422 / 1896 blocks = 0.93 /
 // 2.78 / 3.70 rounds of the 512 resident slots (>= 93% of whole rounds; 128x128 gives 77% at N = 768).
 // The DMA-only ablation of the 128x128 loop already moves ~20 TB/s L2->LDS, i.e. the tile's
