@@ -319,3 +319,21 @@ def test_episode_as_hip_graph_replays_bit_identically():
         outs[ug] = (torch.stack(res).cpu(), pipe.totals().cpu())
         pipe.close()
     assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+
+
+def test_empty_selection_leaves_the_adapters_untouched():
+    """8 views with --filter_ent 1: int(8 * 0.1) == 0 views survive, the reference returns before backward / step
+    (deyo.py:110-113).  The fused episode must do the same: LoRA == snapshot, Adam state zero, logits1 == the
+    un-adapted prediction; and the host surface reports (outputs, 0, 0)."""
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0])
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    xd = torch.from_numpy(x).cuda()
+    base = eng.forward(xd[:1]).clone()
+    l1 = eng.episode(xd, snap, m, v, n_updates=1, mode=1, rho=0.1)       # top-k with k = int(8*0.1) = 0
+    torch.cuda.synchronize()
+    assert torch.equal(flat, snap) and not m.any() and not v.any()
+    assert max_rel(l1.cpu().numpy(), base.cpu().numpy()) < 2e-3           # resumed vs full forward: same weights
+    L = eng.entropy_select_loss(eng.forward(xd), 1, rho=0.1)
+    assert int(L["n"].item()) == 0 and not L["dlogits"].any()
+    eng.close()
