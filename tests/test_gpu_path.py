@@ -337,3 +337,28 @@ def test_empty_selection_leaves_the_adapters_untouched():
     L = eng.entropy_select_loss(eng.forward(xd), 1, rho=0.1)
     assert int(L["n"].item()) == 0 and not L["dlogits"].any()
     eng.close()
+
+
+def test_ragged_calls_inside_a_larger_context():
+    """A context sized for 64 views / 1000 classes serves smaller calls (5 views, then 1, K = 10) with the same
+    results as a context sized exactly, and rejects calls beyond its capacity loudly."""
+    from ttl_amd.engine import TTLEngine
+    from ttl_amd import _lib
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    exact, flat, names = make_engine(cfg, W, lora0, tf, 5)
+    big = TTLEngine(cfg, max_views=64, max_classes=1000, device="cuda:0")
+    big.load_weights(W)
+    big.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
+    flat2 = flat.clone()
+    big.bind_lora(flat2)
+    xd = torch.from_numpy(x).cuda()
+    for n in (5, 1):
+        assert torch.equal(big.forward(xd[:n]), exact.forward(xd[:n]))
+    a = exact.episode(xd[:5], flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat), n_updates=1)
+    b = big.episode(xd[:5], flat2.clone(), torch.zeros_like(flat2), torch.zeros_like(flat2), n_updates=1)
+    assert torch.equal(a, b) and torch.equal(flat, flat2)
+    with pytest.raises(_lib.TtlError):
+        exact.forward(xd[:6])                                            # 6 views into a 5-view context
+    with pytest.raises(_lib.TtlError):
+        exact.set_text_features(torch.zeros(11, cfg.embed), 100.0)       # 11 classes into a 10-class context
+    exact.close(); big.close()
