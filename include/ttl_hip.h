@@ -197,6 +197,11 @@ int ttl_episode_text(ttl_ctx* text_ctx, ttl_ctx* image_ctx, const ttl_episode_ar
 /* C[M,N] = A[M,K](operand dtype, lda) * B[N,K]^T(operand dtype, ldb) -> fp32 C (ldc).  K % 64 == 0, N % 128 == 0. */
 int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
                      int K, void* stream);
+/* Same product with the fused epilogues of the path (modeling_clip.py:309-311,333,346-350): epi 0 = fp32 C; 1 = operand-dtype C
+ * (+ bias); 2 = fp32 C = resid + product + bias; 3 = operand-dtype C = quick_gelu(product + bias).  rows_allocated = rows every
+ * output / resid buffer really has: >= round_up(M, 1280) selects the unguarded big-M kernels the episode uses, 0 the guarded ones. */
+int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epi,
+                    const float* bias, const float* resid, int ldr, int rows_allocated, void* stream);
 /* y = LayerNorm(x) over the last dim (fp32 in, fp32 out, optional mean/rstd [rows]). */
 int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                       float* rstd, int rows, int dim, float eps, void* stream);

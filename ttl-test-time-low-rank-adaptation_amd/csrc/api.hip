@@ -187,7 +187,7 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     const bool big = a0.M >= 1024;   // launch_gemm's own split: the 160x128 kernel vs the latency-bound small-M path
     Prof p(c, big ? 0 : 6, s);
     GemmArgs a = a0;
-    a.padded = 1;   // every arena buffer has Mmax = round_up(N*T, 320) rows
+    a.padded = c->Mmax;   // every big-M arena buffer has Mmax = round_up(N*T, 1280) rows
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
     if (c->prof && big) {
         c->gemm_flops += 2.0 * a.M * a.N * a.K;
@@ -1007,10 +1007,23 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
 int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
     GemmArgs a = {};
     a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
-    static int padded = -1;   // TTL_GEMM_PADDED=1: the caller's C has round_up(M,320) rows -> the unguarded product kernel (bench tools)
-    if (padded < 0) { const char* v = getenv("TTL_GEMM_PADDED"); padded = v ? atoi(v) : 0; }
-    a.padded = padded;
+    // TTL_GEMM_PADDED=1: the caller's C has round_up(M,1280) rows -> the unguarded product kernels (bench tools)
+    static const int padded = [] { const char* v = getenv("TTL_GEMM_PADDED"); return v ? atoi(v) : 0; }();
+    a.padded = padded ? round_up(M, 1280) : 0;
     hipError_t e = launch_gemm(EPI_F32, a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));
+    return 0;
+}
+
+int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epi, const float* bias,
+                    const float* resid, int ldr, int rows_allocated, void* stream) {
+    if (!A || !B || !C) return fail(TTL_EINVAL, "null argument");
+    if (epi < 0 || epi > 3 || (epi == 2 && !resid)) return fail(TTL_EINVAL, "epi must be 0..3 (2 needs resid)");
+    GemmArgs a = {};
+    a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    a.bias = bias; a.resid = resid; a.ldr = ldr;
+    a.padded = rows_allocated >= round_up(M, 1280) ? rows_allocated : 0;
+    hipError_t e = launch_gemm((GemmEpi)epi, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));
     return 0;
 }

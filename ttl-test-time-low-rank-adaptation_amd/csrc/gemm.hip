@@ -15,7 +15,10 @@
 //   * 1-D grid, XCD-aware tile order (n fastest: the A panel of a row tile stays in one L2)
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kernels.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace {
 
@@ -42,83 +45,6 @@ template <int NP, int NP0, int MPER, int DPER>
 struct SchedLoop<NP, NP, NP0, MPER, DPER> {
     static __device__ __forceinline__ void run() {}
 };
-
-// Output stores.  Measured (rocprofv3 --pmc FETCH_SIZE): the 58-155 MB of output a launch writes evict the
-// weight slice / activation panels from the 4 MiB L2s, e.g. fc1 fetches 118 MB where 24 MB are algorithmic;
-// non-temporal stores cut that to 64 MB but the GEMM is not faster (the re-reads hit the Infinity Cache) and
-// the CONSUMER kernels lose their Infinity-Cache hits (attention forward +11 %, episode +3.7 %): plain stores stay.
-#ifndef TTL_GEMM_NT_STORE
-#define TTL_GEMM_NT_STORE 0
-#endif
-// Exception (TTL_GEMM_NT_GELU: 1 = g, 2 = g and u; 2 used): fc1's outputs, 77-155 MB per launch.  g is consumed once by
-// fc2, u only by the backward; storing them non-temporally cuts the launch's HBM-side traffic (all big-M GEMMs: 158 ->
-// 149 MB per launch) and is +0.8 % images/s with one and with three episodes in flight.
-#ifndef TTL_GEMM_NT_GELU
-#define TTL_GEMM_NT_GELU 2
-#endif
-template <typename V>
-__device__ __forceinline__ void st_out(V* p, V v) {
-#if TTL_GEMM_NT_STORE
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-
-// ---- epilogue shared by both kernels: accumulator register r of sub-tile (mt, nt) is row
-// 16*mt + 4*lg + r, column 4*li + nt of the wave's 64-column slab: per (mt, r) a lane owns 4
-// contiguous columns, so one store instruction writes 4 rows x 256 B (fp32) / 128 B (bf16).
-// GUARD = false: the caller guarantees that every row of the last row tile exists in all output /
-// residual / aux buffers (the context pads its arena), so the epilogue is straight-line code: with
-// a per-row branch hipcc re-waits vmcnt(0) in every store block and the stores serialise.
-template <int EPI, int MT, bool GUARD>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg, int M,
-                                              const u32x2 (*auxr)[4] = nullptr) {
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bias = *(const float4*)(a.bias + n0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = rbase + mt * 16 + 4 * lg + r;
-            if (GUARD && m >= M) continue;
-            int pc = m, p2 = m;          // physical rows of C / resid and of C2 (row maps: small-M launches only)
-            if constexpr (GUARD) { if (a.cmap) pc = a.cmap[m]; if (a.c2map) p2 = a.c2map[m]; }
-            float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
-            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
-                size_t orow = pc;
-                if constexpr (EPI == EPI_PATCH) {
-                    int img = m / a.G2, p = m - img * a.G2;
-                    orow = (size_t)img * a.T + 1 + p;
-                    float4 t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
-                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
-                }
-                if constexpr (EPI == EPI_RESID_F32) {
-                    float4 t = *(const float4*)(a.resid + (size_t)pc * a.ldr + n0);
-                    v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
-                }
-                st_out((f32x4*)((float*)a.C + orow * a.ldc + n0), f32x4{v0, v1, v2, v3});
-            } else {
-                if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) {
-                        if (TTL_GEMM_NT_GELU == 2) __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0));
-                        else st_out((u32x2*)(a.C2 + (size_t)p2 * a.ldc2 + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
-                    }
-                    v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
-                }
-                if constexpr (EPI == EPI_GELU_BWD) {
-                    u32x2 t = auxr ? auxr[mt][r] : *(const u32x2*)(a.aux + (size_t)m * a.ldaux + n0);
-                    v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
-                    v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
-                }
-                if (TTL_GEMM_NT_GELU && EPI == EPI_GELU)
-                    __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)((op_t*)a.C + (size_t)pc * a.ldc + n0));
-                else
-                st_out((u32x2*)((op_t*)a.C + (size_t)pc * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
-            }
-        }
-    }
-}
 
 // BM x (64*WNW) block tile, WMW x WNW waves, every wave owns (BM/WMW) x 64 outputs.
 // STAGES == 2: one K-tile in flight, plain __syncthreads().  STAGES > 2 (small-M calls, which are
@@ -339,20 +265,24 @@ template <int BM, int WMW, int WNW, int EPI, bool GUARD = true, int STAGES = 2>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BN = 64 * WNW;
     constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    {   // once per (kernel, device); thread-safe
+        static std::atomic<uint64_t> done{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            if (e != hipSuccess) return e;
+            done.fetch_or(bit, std::memory_order_release);
+        }
     }
     if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     GemmArgs b = a;
     b.xc = 0;
     int nblk = ntm * ntn;
-    static int xcd2d = -1;
-    if (xcd2d < 0) { const char* v = getenv("TTL_GEMM_XCD2D"); xcd2d = v ? atoi(v) : 2; }   // 0 = 1-D order; n = slice limit n*1.5 MiB (+1 % in situ)
+    static const int xcd2d = [] { const char* v = getenv("TTL_GEMM_XCD2D"); return v ? atoi(v) : 2; }();   // 0 = 1-D order; n = slice limit n*1.5 MiB (+1 % in situ)
     if (xcd2d && a.M >= 1024 && a.splits == 1 && ntm >= 8) {
         // columns of the XCD grid: halve the weight slice until it sits comfortably in a 4 MiB L2
         const size_t limit = (size_t)xcd2d * 1536 * 1024;
@@ -399,8 +329,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 // flight), the guarded epilogue and a small tile (see launch_v).
 template <int EPI>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
-    static int variant = -1;
-    if (variant < 0) { const char* v = getenv("TTL_GEMM_VARIANT"); variant = v ? atoi(v) : 2; }
+    static const int variant = [] { const char* v = getenv("TTL_GEMM_VARIANT"); return v ? atoi(v) : 2; }();
     if (a.M < 1024) {
         // Small-M calls (1-view inference, pooled-row GEMMs of the last layer and of its backward: M = 64..257) are
         // latency chains on a handful of blocks, so the tile is SMALL to spread them over more CUs.  In situ, ms of
@@ -439,6 +368,10 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
                                         a.ldc, s, a.cmap);
         }
     }
+    // big-M launches: 256-column tiles (gemm_big.hip) unless switched off (TTL_GEMM_BIG=0: the 160x128 kernel below)
+    static const bool use_big = [] { const char* v = getenv("TTL_GEMM_BIG"); return v ? atoi(v) != 0 : true; }();
+    if (use_big && a.padded && gemm_big_applicable(epi, a) && (size_t)((a.M + 159) / 160) * 160 <= (size_t)a.padded)
+        return launch_gemm_big(epi, a, s);
     switch (epi) {
         case EPI_F32: return launch_v<EPI_F32>(a, s);
         case EPI_OP: return launch_v<EPI_OP>(a, s);

@@ -1,0 +1,434 @@
+// Big-M bf16 MFMA GEMM, 256-column tiles:  C[M,N] = A[M,K] · B[N,K]^T  (+ fused epilogue), M >= 1024.
+//
+// Same products as gemm.hip (HF modeling_clip.py:309-311 q/k/v, :333 out_proj, :346-350 fc1/fc2 and their
+// dgrad counterparts); this kernel exists because the 160x128 tile of gemm.hip stages 1 byte of operand per
+// 71 FLOP and the L2 -> LDS path (one TA per CU) is what bounds it.  Here:
+//   * block tile (32*MT) x 256 x 64, 8 waves as 2 (M) x 4 (N), every wave owns (16*MT) x 64 outputs;
+//     MT = 5: 160 x 256 -> 98 FLOP per staged byte, MT = 7: 224 x 256 -> 119
+//   * ONE block per CU (512 threads); LDS ring of STAGES K-tiles (MT = 5: 3 x 52 KiB = 156 of the 160 KiB),
+//     filled by global_load_lds_dwordx4 behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier: the DMA of
+//     K-tile kt+2 is in flight while kt is multiplied and kt+1 lands (guide §5 "Pipelining across barriers")
+//   * fragments are double-buffered in registers by 32-deep K half: the LDS reads of one half are issued
+//     between the MFMAs of the other (sched_group_barrier), one barrier per K-tile
+//   * LDS image, swizzle, weight-row permutation and the epilogue are those of gemm.hip (gemm_epilogue.hpp)
+//   * persistent tile loop (grid = min(tiles, resident slots)): the first two K-tiles of the NEXT tile are
+//     requested before the epilogue of the current one, so a tile's prologue latency hides under the stores
+//   * tile order: the 8 XCDs own contiguous row-panel ranges; inside an XCD column-major (all row panels of a
+//     256-column weight slice before the next slice: slice + panels fit the 4 MiB L2) or row-major
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "gemm_epilogue.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int BN = 256;
+constexpr int NTHR = 512;
+
+// Diagnostic ablations (tools/gemm_big_ablate.sh builds libttl_hip_bdiagN.so; results are WRONG on purpose, only the
+// timing is read): 1 = no DMA in the steady loop, 2 = no MFMA, 3 = LDS fragment reads from a fixed address (hoisted),
+// 4 = no barrier, 5 = no epilogue stores.  The product build has TTL_GEMM_DIAG == 0 and none of this exists in it.
+#ifndef TTL_GEMM_DIAG
+#define TTL_GEMM_DIAG 0
+#endif
+#if TTL_GEMM_DIAG == 4
+#define BARRIER() ((void)0)
+#else
+#define BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
+// NS slots of {one non-MFMA op, then its share of the NM MFMAs}; the first NV slots are VMEM (the DMA pieces:
+// requested as early as possible), the rest LDS reads
+template <int S, int NS, int NV, int NM>
+struct Mix {
+    static __device__ __forceinline__ void run() {
+        if constexpr (S < NS) {
+            __builtin_amdgcn_sched_group_barrier(S < NV ? 0x010 : 0x100, 1, 0);
+            constexpr int m = NM / NS + (S < NM % NS ? 1 : 0);
+            if constexpr (m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
+            Mix<S + 1, NS, NV, NM>::run();
+        }
+    }
+};
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]),
+// so hipcc's own wait-count pass knows the LDS reads are retired and does not add a second wait behind the barrier
+template <int N>
+__device__ __forceinline__ void wait_dma() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+// Epilogue of this kernel: bias and residual were folded into the accumulators' initial value, so the only memory
+// operations here are stores (an ordinary load next to the next tile's in-flight LDS-DMA makes hipcc wait vmcnt(0),
+// which drains that prefetch).  Register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column 4*li + nt.
+template <int EPI, int MT>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t m = (size_t)(rbase + mt * 16 + 4 * lg + r);
+            float v0 = acc[mt][0][r], v1 = acc[mt][1][r], v2 = acc[mt][2][r], v3 = acc[mt][3][r];
+            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
+                st_out((f32x4*)((float*)a.C + m * a.ldc + n0), f32x4{v0, v1, v2, v3});
+            } else {
+                if constexpr (EPI == EPI_GELU) {
+                    if (a.C2) __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)(a.C2 + m * a.ldc2 + n0));
+                    v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
+                    __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)((op_t*)a.C + m * a.ldc + n0));
+                } else {
+                    st_out((u32x2*)((op_t*)a.C + m * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+                }
+            }
+        }
+    }
+}
+
+struct TileMap {
+    int ntm, ntn;     // row tiles, column tiles
+    int order;        // 0: 1-D XCD chunks, n fastest; 1: XCD row ranges, column-major inside; 2: XCD row ranges, row-major
+    int ntiles;       // order 0: ntm*ntn; else 8 * max_x(rows_x * ntn) slots (some empty)
+};
+
+// slot -> (row tile, column tile); false: the slot is empty
+__device__ __forceinline__ bool tile_of(const TileMap& tm, int slot, int& rt, int& ct) {
+    if (tm.order == 0) {
+        const int t = xcd_remap(slot, tm.ntiles);
+        rt = t / tm.ntn; ct = t - rt * tm.ntn;
+        return true;
+    }
+    const int x = slot & 7, j = slot >> 3;
+    const int r0 = x * tm.ntm / 8, r1 = (x + 1) * tm.ntm / 8, nr = r1 - r0;
+    if (j >= nr * tm.ntn) return false;
+    if (tm.order == 1) { ct = j / nr; rt = r0 + (j - ct * nr); }
+    else { const int jr = j / tm.ntn; rt = r0 + jr; ct = j - jr * tm.ntn; }
+    return true;
+}
+
+template <int MT, int STAGES, int EPI>
+__global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, const TileMap tm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    constexpr int BM = 32 * MT, WM = 16 * MT;
+    constexpr int NAP = BM / 8;               // 1 KiB DMA pieces (one wave instruction: 8 rows x 128 B) of the A tile
+    constexpr int NPIECE = NAP + BN / 8;
+    constexpr int NPW = (NPIECE + 7) / 8;     // pieces of the waves that carry the most
+    constexpr int NFULL = NPIECE % 8;         // waves [0, NFULL) carry NPW pieces, the others NPW - 1 (0: all NPW)
+    constexpr int NUNI = NFULL ? NPW - 1 : NPW;   // pieces every wave carries
+    constexpr int A_BYTES = BM * 128;
+    constexpr int STAGE = A_BYTES + BN * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int M = a.M;
+    const int nk = a.K / BK;
+
+    // ---- fragment addresses: row (tile row + li) of a 128-B-per-row image, 16-B chunk (4s + lg) ^ swizzle(row)
+    const int swA = (li >> 1) & 7;
+    const int fA0 = (wm * WM + li) * 128 + ((lg ^ swA) << 4);
+    const int fW0 = A_BYTES + (wn * 64 + li) * 128 + ((lg ^ swA) << 4);
+    auto load_frags = [&](const char* sb, int s, opx8 (&xf)[MT], opx8 (&wf)[4]) {
+        if (TTL_GEMM_DIAG == 3) sb = smem;
+        const char* pa = sb + (fA0 ^ (s << 6));
+        const char* pw = sb + (fW0 ^ (s << 6));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const opx8*)(pa + mt * 2048);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const opx8*)(pw + nt * 2048);
+    };
+
+    // ---- DMA pieces of this wave: piece j = i*8 + wave covers image rows 8j' .. 8j'+7 of A (j < NAP) or B
+    uint32_t poff[NPW];
+    const char* pbase[NPW];
+    int plds[NPW];
+    auto setup = [&](int row0, int col0) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int j = i * 8 + wave;
+            const int jj = (j < NAP) ? j : j - NAP;
+            const int r = jj * 8 + (lane >> 3), p = lane & 7;
+            const int c = p ^ ((r >> 1) & 7);
+            if (j < NAP) {
+                const int gr = min(row0 + r, M - 1);
+                poff[i] = (uint32_t)(((size_t)gr * a.lda + c * 8) * sizeof(op_t));
+                pbase[i] = (const char*)a.A;
+                plds[i] = j * 1024;
+            } else {
+                const int n = (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);   // physical LDS row r holds this output column
+                poff[i] = (uint32_t)(((size_t)(col0 + n) * a.ldb + c * 8) * sizeof(op_t));
+                pbase[i] = (const char*)a.B;
+                plds[i] = A_BYTES + jj * 1024;
+            }
+        }
+    };
+    auto issue_odd = [&](int kt, char* sb) {    // the piece only waves [0, NFULL) carry: wave-uniform branch, kept out of
+        if constexpr (NFULL != 0) {            // the scheduled region
+            if (TTL_GEMM_DIAG == 1 && kt >= 2) return;
+            if (wave < NFULL)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pbase[NPW - 1] + (size_t)kt * (BK * sizeof(op_t)) + poff[NPW - 1]),
+                                                 LDS_PTR(sb + plds[NPW - 1]), 16, 0, 0);
+        }
+    };
+    auto issue_uni = [&](int kt, char* sb) {
+        if (TTL_GEMM_DIAG == 1 && kt >= 2) return;
+#pragma unroll
+        for (int i = 0; i < NUNI; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pbase[i] + (size_t)kt * (BK * sizeof(op_t)) + poff[i]), LDS_PTR(sb + plds[i]), 16, 0,
+                                             0);
+    };
+    // wait until at most `tiles` of this wave's K-tiles of DMA are still in flight (+ all LDS reads retired)
+    auto wait_tiles1 = [&]() {
+        if constexpr (NFULL != 0) { if (wave < NFULL) wait_dma<NPW>(); else wait_dma<NPW - 1>(); }
+        else wait_dma<NPW>();
+    };
+    // the same while the previous tile's epilogue stores (at least NST of them, issued AFTER the K-tile waited for and
+    // before the one left in flight) may still be unacknowledged: vmcnt counts loads and stores together, in order
+    constexpr int NST = 4 * MT;
+    auto wait_tiles1_st = [&]() {
+        if constexpr (NFULL != 0) { if (wave < NFULL) wait_dma<NPW + NST>(); else wait_dma<NPW - 1 + NST>(); }
+        else wait_dma<NPW + NST>();
+    };
+    // bias of the tile's 4 columns of this lane: fetched by inline asm (invisible to hipcc's wait-count pass, which would
+    // answer an ordinary load beside in-flight LDS-DMA with vmcnt(0)) BEFORE the tile's first DMA, so the counted wait at
+    // the top of the tile covers it
+    f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_bias = [&](int col0) {
+        if (a.bias) {
+            const float* bp = a.bias + col0 + wn * 64 + 4 * li;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(biasv) : "v"(bp) : "memory");
+        }
+    };
+
+    f32x4 acc[MT][4];
+    opx8 xf0[MT], wf0[4], xf1[MT], wf1[4];
+    auto mma = [&](const opx8 (&xf)[MT], const opx8 (&wf)[4]) {
+        if (TTL_GEMM_DIAG == 2) {   // keep the LDS reads alive without the matrix pipe
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(xf[mt]));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(wf[nt]));
+            return;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+    };
+
+    int slot = blockIdx.x;
+    int rt, ct;
+    bool have = tile_of(tm, slot, rt, ct);
+    while (!have) {     // (empty slots of an uneven XCD row split)
+        slot += gridDim.x;
+        if (slot >= tm.ntiles) return;
+        have = tile_of(tm, slot, rt, ct);
+    }
+    int row0 = rt * BM, col0 = ct * BN;
+    setup(row0, col0);
+    char* s0 = smem;
+    char* s1 = smem + STAGE;
+    char* s2 = smem + (STAGES == 3 ? 2 * STAGE : 0);
+    // ring prologue of the first tile
+    fetch_bias(col0);
+    issue_odd(0, s0); issue_uni(0, s0);
+    if constexpr (STAGES == 3) { issue_odd(1, s1); issue_uni(1, s1); }
+
+    bool first = true;
+    for (;;) {
+        // residual tile (EPI_RESID_F32): read at the TOP of the tile, where it overlaps the DMA prologue, instead of at the
+        // end where all blocks of a launch would read theirs at once with the matrix pipe idle
+        f32x4 rsd[EPI == EPI_RESID_F32 ? MT : 1][4];
+        if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rsd[mt][r] = *(const f32x4*)(a.resid + (size_t)(row0 + wm * WM + mt * 16 + 4 * lg + r) * a.ldr + col0 + wn * 64 + 4 * li);
+        }
+        char *cur = s0, *nxt = s1, *nn = s2;
+        // K-tile 0 landed (STAGES == 3: K-tile 1 may still fly), and with it the bias
+        if constexpr (STAGES == 3) { if (first) wait_tiles1(); else wait_tiles1_st(); }
+        else { if (first) wait_dma<0>(); else wait_dma<NST>(); }
+        asm volatile("" : "+v"(biasv));
+        BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAGES == 2) { issue_odd(1, nxt); issue_uni(1, nxt); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if constexpr (EPI == EPI_RESID_F32)
+                    acc[mt][nt] = f32x4{rsd[mt][0][nt] + biasv[nt], rsd[mt][1][nt] + biasv[nt], rsd[mt][2][nt] + biasv[nt], rsd[mt][3][nt] + biasv[nt]};
+                else
+                    acc[mt][nt] = f32x4{biasv[nt], biasv[nt], biasv[nt], biasv[nt]};
+            }
+        load_frags(cur, 0, xf0, wf0);
+
+        // ---- steady state: step kt multiplies K-tile kt; requests kt+2 (3 stages: at the top, into the stage freed by
+        // barrier kt-1; 2 stages: behind barrier kt, into the stage just read); one barrier per step
+        for (int kt = 0; kt + 2 < nk; ++kt) {
+            if constexpr (STAGES == 3) {
+                issue_odd(kt + 2, nn);
+                issue_uni(kt + 2, nn);
+            }
+            load_frags(cur, 1, xf1, wf1);
+            mma(xf0, wf0);
+            if constexpr (STAGES == 3) Mix<0, NUNI + MT + 4, NUNI, 4 * MT>::run();
+            else Mix<0, MT + 4, 0, 4 * MT>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            // K-tile kt+1 landed; h1 reads of kt retired
+            if constexpr (STAGES == 3) { if (kt == 0 && !first) wait_tiles1_st(); else wait_tiles1(); }
+            else wait_dma<0>();
+            BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAGES == 2) { issue_odd(kt + 2, cur); issue_uni(kt + 2, cur); }
+            load_frags(nxt, 0, xf0, wf0);
+            mma(xf1, wf1);
+            if constexpr (STAGES == 3) Mix<0, MT + 4, 0, 4 * MT>::run();
+            else Mix<0, NUNI + MT + 4, NUNI, 4 * MT>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAGES == 3) { char* t = cur; cur = nxt; nxt = nn; nn = t; }
+            else { char* t = cur; cur = nxt; nxt = t; }
+        }
+        // ---- step nk-2: nothing left to request for this tile
+        {
+            load_frags(cur, 1, xf1, wf1);
+            mma(xf0, wf0);
+            Mix<0, MT + 4, 0, 4 * MT>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_dma<0>();
+            BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- next tile of this block: request its first K-tiles now (every stage but `nxt` is free behind the barrier
+        // above: `cur` was read before it, `nn` two steps ago), so they land under step nk-1 and the epilogue
+        int nslot = slot + gridDim.x, nrt = 0, nct = 0;
+        bool more = false;
+        while (nslot < tm.ntiles && !(more = tile_of(tm, nslot, nrt, nct))) nslot += gridDim.x;
+        const int erow0 = row0, ecol0 = col0;
+        if (more) {
+            row0 = nrt * BM; col0 = nct * BN;
+            setup(row0, col0);
+            fetch_bias(col0);
+            issue_odd(0, cur); issue_uni(0, cur);
+            if constexpr (STAGES == 3) { issue_odd(1, nn); issue_uni(1, nn); }
+        }
+        // ---- step nk-1
+        {
+            load_frags(nxt, 0, xf0, wf0);
+            mma(xf1, wf1);
+            Mix<0, MT + 4, 0, 4 * MT>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(nxt, 1, xf1, wf1);
+            mma(xf0, wf0);
+            mma(xf1, wf1);
+        }
+        if (TTL_GEMM_DIAG == 5) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
+        } else big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+        if (!more) break;
+        slot = nslot;
+        first = false;
+        // ring order of the next tile: K-tile 0 sits in `cur`, K-tile 1 in `nn` (3 stages); everyone must be done
+        // reading `nxt` (step nk-1) before K-tile 2 goes there: the barrier at the top of the tile orders that
+        if constexpr (STAGES == 3) { s0 = cur; s1 = nn; s2 = nxt; }
+        else { s0 = cur; s1 = nxt; }
+    }
+}
+
+// hipFuncSetAttribute once per (kernel, device); thread-safe
+inline hipError_t ensure_smem(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int MT, int STAGES, int EPI>
+hipError_t launch_big_t(const GemmArgs& a, int order, int max_blocks, hipStream_t s) {
+    constexpr int BM = 32 * MT;
+    constexpr int SMEM = STAGES * (BM + BN) * 128;
+    static std::atomic<uint64_t> done{0};
+    hipError_t e = ensure_smem((const void*)gemm_big_kernel<MT, STAGES, EPI>, SMEM, done);
+    if (e != hipSuccess) return e;
+    TileMap tm;
+    tm.ntm = (a.M + BM - 1) / BM; tm.ntn = a.N / BN; tm.order = order;
+    if (order == 0 || tm.ntm < 8) { tm.order = 0; tm.ntiles = tm.ntm * tm.ntn; }
+    else { tm.ntiles = 8 * ((tm.ntm + 7) / 8) * tm.ntn; }
+    int grid = tm.ntiles < max_blocks ? tm.ntiles : max_blocks;
+    if (tm.order != 0) grid = (grid / 8) * 8 ? (grid / 8) * 8 : 8;   // whole XCD rounds: slot & 7 must stay the block's XCD label
+    hipLaunchKernelGGL((gemm_big_kernel<MT, STAGES, EPI>), dim3(grid), dim3(NTHR), SMEM, s, a, tm);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_big_v(const GemmArgs& a, int mt, int stages, int order, int max_blocks, hipStream_t s) {
+    if (mt == 5 && stages == 3) return launch_big_t<5, 3, EPI>(a, order, max_blocks, s);
+    if (mt == 5 && stages == 2) return launch_big_t<5, 2, EPI>(a, order, max_blocks, s);
+    if (mt == 7) return launch_big_t<7, 2, EPI>(a, order, max_blocks, s);
+    if (mt == 8) return launch_big_t<8, 2, EPI>(a, order, max_blocks, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// rows the kernel may store for a launch of M rows with row tiles of 32*mt (unguarded epilogue)
+bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
+    if (epi == EPI_PATCH) return false;                       // scattered output rows: guarded kernel of gemm.hip
+    if (epi == EPI_GELU_BWD) return false;                    // its epilogue reads u: 8*MT registers fetched ahead, gemm.hip has them
+    if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3) return false;
+    if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
+    return true;
+}
+
+hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
+    // Tile height (TTL_GEMM_BIG_MT), ring depth, tile order, resident blocks: tuned in situ, see DESIGN.md §3.1
+    static const int mt_env = env_int("TTL_GEMM_BIG_MT", 5);
+    static const int st_env = env_int("TTL_GEMM_BIG_STAGES", 0);
+    static const int order_env = env_int("TTL_GEMM_BIG_ORDER", -1);
+    static const int blocks_env = env_int("TTL_GEMM_BIG_BLOCKS", 0);
+    static std::atomic<int> ncu{0};
+    int cus = ncu.load();
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorInvalidDevice;
+        cus = p.multiProcessorCount; ncu.store(cus);
+    }
+    int mt = mt_env;
+    if ((size_t)((a.M + 32 * mt - 1) / (32 * mt)) * 32 * mt > (size_t)a.padded) mt = 5;   // a.padded = rows every output buffer has
+    if ((size_t)((a.M + 159) / 160) * 160 > (size_t)a.padded) return hipErrorInvalidValue;
+    const int stages = (mt == 5) ? (st_env ? st_env : 3) : 2;
+    const int ntn = a.N / BN, ntm = (a.M + 32 * mt - 1) / (32 * mt);
+    // column-major inside an XCD when its tiles take more than one round (the weight slice stays in L2 while the
+    // row panels cycle); row-major when everything is resident at once (a panel's column tiles run side by side)
+    int order = order_env >= 0 ? order_env : ((ntm * ntn > cus) ? 1 : 2);
+    const int max_blocks = blocks_env ? blocks_env : cus;
+    switch (epi) {
+        case EPI_F32: return launch_big_v<EPI_F32>(a, mt, stages, order, max_blocks, s);
+        case EPI_OP: return launch_big_v<EPI_OP>(a, mt, stages, order, max_blocks, s);
+        case EPI_RESID_F32: return launch_big_v<EPI_RESID_F32>(a, mt, stages, order, max_blocks, s);
+        case EPI_GELU: return launch_big_v<EPI_GELU>(a, mt, stages, order, max_blocks, s);
+        default: break;
+    }
+    return hipErrorInvalidValue;
+}

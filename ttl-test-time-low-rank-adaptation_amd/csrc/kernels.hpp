@@ -26,7 +26,7 @@ struct GemmArgs {
     const float* pos; int G2; int T; // EPI_PATCH
     float* ws; size_t ws_bytes;   // optional split-K workspace (small-M fp32-output calls)
     int splits;                   // internal: K slices of this launch (blockIdx.y)
-    int padded;                   // all C/resid/aux/C2 buffers have rows up to round_up(M, 320): unguarded epilogue allowed
+    int padded;                   // rows every C/resid/aux/C2 buffer really has (>= round_up(M, 320): unguarded epilogue allowed); 0 = unknown
     int xc;                       // internal: columns of the 2-D XCD grid (0 = 1-D tile order)
     // Row maps (small-M launches only, M < 1024): logical row m lives at physical row map[m] of the buffer.
     // Lets the last text-tower layer run on the pooled (end-of-text) row of every prompt in place.
@@ -35,6 +35,10 @@ struct GemmArgs {
     const int* c2map;             // C2 rows
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+// gemm_big.hip: (32*MT) x 256 tiles, 8 waves, one persistent block per CU; big-M launches whose output buffers have
+// `a.padded` >= round_up(M, tile rows) rows (unguarded epilogue)
+bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a);
+hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 hipError_t launch_cast_f32_op(const float* src, op_t* dst, size_t n, hipStream_t s);
