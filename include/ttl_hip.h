@@ -230,11 +230,13 @@ int ttl_make_views(const unsigned char* image_hwc, int height, int width, const 
                    void* stream);
 
 /* Copy an internal buffer to the host (synchronises): name in {"h_in","h_mid","h_out","qkv",
- * "attn_out","x1","u","lse","dh","features","lora_grads"}; layer indexes encoder layers where it applies. */
+ * "attn_out","x1","u","lse","dh","features","lora_grads"}; layer indexes encoder layers where it applies.
+ * Also what the last fused update really used: "idx" (int64 selection list, the reference's order: deyo.py:103-108 /
+ * ttl.py:50-54), "n_selected" (int32), "entropy" (fp32 per view). */
 int ttl_debug_copy(ttl_ctx* ctx, const char* name, int layer, void* host_dst, size_t bytes);
 
 /* Per-kernel-class device time of the calls made while profiling is on (HIP events on `stream`).
- * classes: 0 gemm (the big-M 160x128 kernel: M >= 1024), 1 attention fwd, 2 attention bwd, 3 layernorm/elementwise,
+ * classes: 0 gemm (the big-M kernels, M >= 1024: 160x256 tiles of gemm_big.hip, 160x128 of gemm.hip), 1 attention fwd, 2 attention bwd, 3 layernorm/elementwise,
  * 4 lora, 5 head/loss/opt, 6 small-M gemm (1-view inference, CLS-row GEMMs: latency-bound 128x128 launches).
  * gemm_flops / ttl_profile_gemm_bytes cover class 0 only.
  * ttl_profile_read synchronises and returns accumulated milliseconds and launch counts. */
@@ -245,6 +247,8 @@ int ttl_profile_read(ttl_ctx* ctx, double ms[TTL_NCLASS], long long launches[TTL
 /* Algorithmic bytes (operands + outputs + fused epilogue inputs, each once) of the GEMM launches covered by the
  * last ttl_profile_read: the denominator the measured HBM traffic of those launches is compared with. */
 int ttl_profile_gemm_bytes(ttl_ctx* ctx, double* bytes);
+/* 2*M*N*K summed over ALL GEMM launches (classes 0 and 6) covered by the last ttl_profile_read: the executed matrix FLOPs. */
+int ttl_profile_gemm_flops_all(ttl_ctx* ctx, double* flops);
 
 #ifdef __cplusplus
 }

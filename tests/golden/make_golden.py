@@ -46,6 +46,9 @@ CASES = {
     "b16_n8_k10": ("ViT-B/16", 8, 10, {}),
     "b16_n64_k200_ent0": ("ViT-B/16", 64, 200, {}),
     "b16_n64_k200_ent1": ("ViT-B/16", 64, 200, {"filter_ent": 1}),
+    # BASELINE.json configs[2]'s single-GPU workload: the 1000 ImageNet labels
+    "b16_n64_k1000_ent0": ("ViT-B/16", 64, 1000, {}),
+    "b16_n64_k1000_ent1": ("ViT-B/16", 64, 1000, {"filter_ent": 1}),
 }
 
 

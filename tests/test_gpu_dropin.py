@@ -208,3 +208,116 @@ def test_plpd_filter_matches_reference(name):
         out = model(x[:1])
     assert max_rel(out.cpu().numpy(), g["logits1"]) < 5e-3
     assert int(out.argmax()) == int(g["top5"][0, 0])
+
+
+def test_reference_plpd_body_through_autograd():
+    """The REFERENCE's formulation of the PLPD step (deyo.py:97-151,175-188) in torch on top of model(x): model(x) with
+    grad, a SECOND grad-enabled model(x_prime) on the destroyed views (deyo.py:136), then loss.backward() through the first
+    forward only.  The second forward must not clobber the first one's saved activations (it lands in the auxiliary
+    context); pinned by the reference-generated fixture."""
+    from ttl_amd import deyo as D
+    g, cfg, model, opt, opt_state, x = build("tiny_plpd")
+    model.precision = "fp16"
+    args = ref_args(filter_plpd=1, plpd_threshold=float(g["plpd_threshold"]), aug_type="patch", patch_len=int(g["patch_len"]))
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.load_state_dict(opt_state)
+    torch.manual_seed(int(g["rng_seed"]))
+    outputs = model(x)
+    entropys = -(outputs.softmax(1) * outputs.log_softmax(1)).sum(1)
+    ids1 = torch.where(entropys <= math.log(1000))
+    entropys = entropys[ids1]
+    x_prime = D.plpd_views(x[ids1].detach(), args)
+    outputs_prime = model(x_prime)                          # grad enabled, like the reference
+    assert outputs_prime.requires_grad
+    prob, prob_p = outputs[ids1].softmax(1), outputs_prime.softmax(1)
+    cls1 = prob.argmax(dim=1)
+    plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_p, 1, cls1.reshape(-1, 1))).reshape(-1)
+    ids2 = torch.where(plpd > args.plpd_threshold)
+    entropys = entropys[ids2]
+    assert len(entropys) == len(g["idx2"])
+    coeff = 1 * (1 / torch.exp(entropys.clone().detach() - 0.4))
+    loss = entropys.mul(coeff).mean(0)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    lora1 = named_lora(model, cfg)
+    frac_bad = np.mean([float((np.abs(lora1[k] - g["lora1/" + k]) > 1e-3).mean()) for k in lora1])
+    assert frac_bad < 0.05, frac_bad
+    with torch.no_grad():
+        out = model(x[:1])
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 5e-3
+
+
+def test_stale_saved_activations_are_refused():
+    """Three grad-enabled forwards before any backward: two contexts can hold two of them; the oldest one's
+    activations are gone and its backward must fail loudly instead of producing gradients from other views."""
+    from ttl_amd._lib import TtlError
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    with torch.no_grad():
+        model.LoRA_reset()
+    a = model(x)
+    b = model(x.flip(0).contiguous())
+    c = model(x * 0.5)
+    with pytest.raises(TtlError):
+        a.sum().backward()
+    opt.zero_grad()
+    c.sum().backward()               # the two newest are intact
+    gc = [p.grad.clone() for p in model.trainable_lora_parameters()]
+    opt.zero_grad()
+    b.sum().backward()
+    gb = [p.grad.clone() for p in model.trainable_lora_parameters()]
+    # and they are the gradients of THEIR views: equal to a fresh forward/backward of the same input
+    with torch.no_grad():
+        model.LoRA_reset()
+    opt.zero_grad()
+    model(x * 0.5).sum().backward()
+    for p, q in zip(model.trainable_lora_parameters(), gc):
+        assert torch.equal(p.grad, q)
+    opt.zero_grad()
+    model(x.flip(0).contiguous()).sum().backward()
+    for p, q in zip(model.trainable_lora_parameters(), gb):
+        assert torch.equal(p.grad, q)
+
+
+def test_aux_context_follows_a_label_set_of_the_same_size():
+    """reset_classnames() to another label set with the SAME class count (ImageNet-A -> ImageNet-R) must refresh the
+    class embeddings of the auxiliary (PLPD) context too."""
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    model._ensure_engine()
+    aux = model._aux_engine()
+    z_main = model.engine.forward(x[:2]).clone()
+    assert torch.equal(aux.forward(x[:2]), z_main)
+    tf2 = torch.roll(model.text_features, 3, dims=0).contiguous()       # "another dataset", same K
+    model.get_text_features = lambda: tf2
+    model._text_dirty = True
+    z2 = model._ensure_engine().forward(x[:2]).clone()
+    assert not torch.equal(z2, z_main)
+    assert torch.equal(model._aux_engine().forward(x[:2]), z2)
+
+
+def test_eval_routes_filter_plpd_to_the_stepwise_loop():
+    """test_time_adapt_eval with --filter_plpd 1 == the reference-shaped per-image loop with the PLPD filter (not a silent
+    plain-DeYO run); the fused runner refuses the flag."""
+    from ttl_amd.eval import test_time_adapt_eval, SyntheticViews
+    from ttl_amd.ttl import test_time_tuning
+    from ttl_amd.driver import topk_hits, EpisodeRunner
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    args = ref_args(filter_plpd=1, plpd_threshold=-1.0, aug_type="occ", occlusion_size=8, row_start=4, column_start=4, patch_len=4)
+    with pytest.raises(NotImplementedError):
+        EpisodeRunner(model, args)
+    data = SyntheticViews(cfg, 4, 8, 10, seed=5)
+    hits = torch.zeros(2, dtype=torch.int64)
+    outs = []
+    for views, label in data:
+        with torch.no_grad():
+            model.LoRA_reset()
+        opt.load_state_dict(opt_state)
+        test_time_tuning(model, views.cuda(), opt, None, args)
+        with torch.no_grad():
+            out = model(views[:1].cuda())
+        outs.append(out)
+        h1, h5 = topk_hits(out.cpu(), torch.tensor([label]))
+        hits += torch.stack([h1, h5])
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=2)
+    assert abs(top1 - 100.0 * hits[0].item() / 4) < 1e-9 and abs(top5 - 100.0 * hits[1].item() / 4) < 1e-9

@@ -68,6 +68,13 @@ def test_episode(name):
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
     assert np.array_equal(np.sort(idx), np.sort(g["idx"])), "confidence-selection set differs from the reference"
     n_up = kw["n_updates"]
+    if n_up == 1:
+        # ... and the list the HIP episode itself used (idx_buf of select_kernel).  The SET is the reference's; the ORDER
+        # inside a top-k list follows the entropies, which carry operand-rounding noise end to end (given the same logits
+        # the order is the reference's too: test_gpu_kernels.py::test_entropy_select_loss_vs_reference)
+        hip_idx, hip_H = eng.last_selection(x.shape[0])
+        assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1))), (hip_idx, g["idx"])
+        np.testing.assert_allclose(hip_H, g["H"], rtol=0, atol=5e-2)
     lora1 = split(flat, lora0, names)
     grads = split(eng.grads, lora0, names)
     for k in names:
@@ -139,9 +146,9 @@ def test_errors_are_loud():
 
 
 # ------------------------------------------------------------------ full-size geometries
-@pytest.mark.parametrize("name", ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1"])
+@pytest.mark.parametrize("name", ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1"])
 def test_vit_b16_against_reference_goldens(name):
-    """BASELINE configs 1-3 shapes (ViT-B/16, r=16; 8 views/K=10 and 64 views/K=200) vs the outputs
+    """BASELINE configs 1-3 shapes (ViT-B/16, r=16; 8 views/K=10, 64 views/K=200 and 64 views/K=1000) vs the outputs
     of the reference itself.  bf16 MFMA operands cost 3-5e-3 of the logit range on this model
     (the bf16-emulating oracle sits at the same distance: tests/diag_path.py), the selection set
     is still exactly the reference's."""
@@ -159,6 +166,8 @@ def test_vit_b16_against_reference_goldens(name):
     np.testing.assert_allclose(H, g["H"], rtol=0, atol=2.5e-2)
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
     assert np.array_equal(np.sort(idx), np.sort(g["idx"])), "confidence-selection set differs from the reference"
+    hip_idx, _ = eng.last_selection(x.shape[0])     # the list the HIP episode itself used (set; order: see test_episode)
+    assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1))), (hip_idx, g["idx"])
     lora1 = split(flat, lora0, names)
     grads = split(eng.grads, lora0, names)
     for k in names:
@@ -204,6 +213,72 @@ def test_other_geometries_forward_and_step_vs_oracle(arch):
     eng.close()
 
 
+def test_vit_l14_64_views():
+    """BASELINE config 4 at its full size (ViT-L/14, r=16, 64 views, K=200: M = 64*257 = 16448 token rows, 257-token
+    attention tiles, row tiles that end inside the arena's padding).  The reference cannot run L/14 (Q8) and the CPU
+    oracle takes minutes at 64 views, so: (1) size-independent properties at 64 views — bitwise determinism, complete
+    episodic reset, resumed == full forward, per-view independence (logits of views 0..7 inside the 64-view batch ==
+    the 8-view forward's); (2) the 8-view episode against the bf16-emulating oracle."""
+    from ttl_amd import synth
+    from ttl_amd.config import get_config
+    cfg = get_config("ViT-L/14")
+    W = synth.vision_weights(cfg, 0)
+    lora0 = synth.lora_init(cfg, 0)
+    xh = synth.views(cfg, 64, 5)
+    x = torch.from_numpy(xh).cuda()
+    tf = synth.text_features(200, cfg.embed)
+    eng, flat, names = make_engine(cfg, W, lora0, tf, 64)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    a, z64 = eng.episode(x, snap, m, v, want_logits0=True)
+    a, z64, p_a = a.clone(), z64.clone(), flat.clone()
+    idx64, _ = eng.last_selection(64)
+    b = eng.episode(x, snap, m, v).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(p_a, flat)                  # bitwise reproducible + complete reset
+    assert len(idx64) == 64 and torch.isfinite(a).all() and torch.isfinite(z64).all()
+    full = eng.forward(x[:1])
+    assert max_rel(full.cpu().numpy(), a.cpu().numpy()) < 2e-3          # resumed-at-layer-21 == full forward (bf16 noise level)
+    # 8 views: the same context, vs the oracle
+    l1, l0 = eng.episode(x[:8], snap, m, v, want_logits0=True)
+    torch.cuda.synchronize()
+    assert max_rel(l0.cpu().numpy(), z64[:8].cpu().numpy()) < 1e-5       # a view's logits do not depend on its batch
+    trace = []
+    ob = O.episode(cfg, W, lora0, xh[:8], tf, prec="bf16", trace=trace)
+    assert max_rel(l0.cpu().numpy(), ob["logits0"]) < 1e-2
+    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 1e-2
+    grads = split(eng.grads, lora0, names)
+    for k in names:
+        gr = trace[-1]["grads"][k]
+        if np.abs(gr).max() > 0:
+            assert max_rel(grads[k], gr) < 2.5e-2, k
+    eng.close()
+
+
+def test_r32_16_views_4_updates_vs_oracle():
+    """BASELINE config 5's algorithm (ViT-B/16, r=32, 4 optimizer updates, top-k selection, K=1000) at 16 views, where the
+    bf16-emulating oracle finishes in seconds: logits after 4 updates, the selection list of the last update and the
+    adapted prediction.  (The 128-view size runs in test_r32_128_views_multi_step_invariants.)"""
+    from ttl_amd import synth
+    from ttl_amd.config import get_config
+    cfg = get_config("ViT-B/16").replace(rank=32)
+    W = synth.vision_weights(cfg, 0)
+    lora0 = synth.lora_init(cfg, 0)
+    xh = synth.views(cfg, 16, 9)
+    tf = synth.text_features(1000, cfg.embed)
+    eng, flat, names = make_engine(cfg, W, lora0, tf, 16)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    l1, l0 = eng.episode(torch.from_numpy(xh).cuda(), snap, m, v, n_updates=4, mode=1, rho=0.25, want_logits0=True)
+    torch.cuda.synchronize()
+    ob = O.episode(cfg, W, lora0, xh, tf, prec="bf16", mode="topk", rho=0.25, n_updates=4)
+    assert max_rel(l0.cpu().numpy(), ob["logits0"]) < 1e-2
+    # 4 sign-like AdamW steps of lr amplify operand-rounding differences in the adapters; the adapted logits still agree
+    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 3e-2
+    assert int(l1.argmax()) == int(np.argmax(ob["logits1"]))
+    hip_idx, _ = eng.last_selection(16)
+    assert len(hip_idx) == int(16 * 0.25)
+    eng.close()
+
+
 def test_r32_128_views_multi_step_invariants():
     """BASELINE config 5 shape (ViT-B/16, r=32, 128 views, 4 TTA steps, K=1000): too big for the CPU
     oracle inside a test, so check size-independent properties: determinism across runs, episodic
@@ -233,7 +308,8 @@ def test_r32_128_views_multi_step_invariants():
 
 
 # ------------------------------------------------------------------ fp16-operand build (the reference's autocast dtype)
-@pytest.mark.parametrize("name", ["tiny_deyo", "tiny197_deyo", "b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1"])
+@pytest.mark.parametrize("name", ["tiny_deyo", "tiny197_deyo", "b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1",
+                                  "b16_n64_k1000_ent0", "b16_n64_k1000_ent1"])
 def test_fp16_operands_meet_the_1e3_tolerance(name):
     """libttl_hip_fp16.so: same kernels with IEEE-half MFMA operands (what torch.cuda.amp.autocast() uses in
     the reference's GPU path, ttl.py:79) and a fixed 2^10 loss scale in the backward (cf. GradScaler,
@@ -255,6 +331,8 @@ def test_fp16_operands_meet_the_1e3_tolerance(name):
     H = O.softmax_entropy(z0)
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
     assert np.array_equal(np.sort(idx), np.sort(g["idx"]))
+    hip_idx, _ = eng.last_selection(x.shape[0])
+    assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1))), (hip_idx, g["idx"])
     lora1 = split(flat, lora0, names)
     grads = split(eng.grads, lora0, names)
     for k in names:

@@ -91,7 +91,7 @@ def test_episode_b16_n8_k10():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1"])
+@pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent1"])
 def test_episode_b16_n64(name):
     _run_case(name, check_taps=False)
 

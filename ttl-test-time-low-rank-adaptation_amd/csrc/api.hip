@@ -109,7 +109,7 @@ struct ttl_ctx {
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
     bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
-    bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_bytes = 0, gemm_bytes_last = 0;
+    bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_flops_all = 0, gemm_flops_all_last = 0, gemm_bytes = 0, gemm_bytes_last = 0;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
 
@@ -187,8 +187,12 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     const bool big = a0.M >= 1024;   // launch_gemm's own split: the 160x128 kernel vs the latency-bound small-M path
     Prof p(c, big ? 0 : 6, s);
     GemmArgs a = a0;
-    a.padded = c->Mmax;   // every big-M arena buffer has Mmax = round_up(N*T, 1280) rows
+    // token-row buffers ([n*T, .]) have Mmax = round_up(max_views*T, 1280) rows: whole row tiles may be stored unguarded.
+    // The compact [n, .] buffers of the pooled last layer / CLS-only top-layer backward have exactly max_views rows:
+    // guarded kernels, whatever n is.
+    a.padded = (a0.M > c->c.max_views) ? c->Mmax : 0;
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
+    if (c->prof) c->gemm_flops_all += 2.0 * a.M * a.N * a.K;
     if (c->prof && big) {
         c->gemm_flops += 2.0 * a.M * a.N * a.K;
         // algorithmic bytes of the launch: both operands once, every output once, the fused epilogue inputs once
@@ -579,9 +583,9 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
-        static int pooled_last = -1;   // TTL_POOLED_LAST_LAYER=0: run the last layer densely (A/B and the equivalence test)
-        if (pooled_last < 0) { const char* v = getenv("TTL_POOLED_LAST_LAYER"); pooled_last = v ? atoi(v) : 1; }
-        if (pooled_last && i == c->L - 1 && (!c->text || n < 1024)) {   // (row maps exist in the small-M GEMM kernels only)
+        // TTL_POOLED_LAST_LAYER=0: run the last layer densely (A/B and the equivalence test)
+        static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
+        if (pooled_last && i == c->L - 1 && n < 1024) {   // (row maps / compact [n, .] buffers: guarded small-M GEMM kernels only)
             // ---- last layer: the head reads ONE row per sequence (image tower: CLS, HF modeling_clip.py pooled =
             // last_hidden_state[:, 0]; text tower: the end-of-text token), so beyond K and V of every token everything
             // runs on those n rows: the query projection, attention for that query, out_proj, LN2 and the MLP — in place,
@@ -762,9 +766,8 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             const op_t* u_rows = l.u; int ld_u = T * F;
             const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
             const float *mu2 = l.mu2, *rs2 = l.rs2;
-            static int pooled_last = -1;
-            if (pooled_last < 0) { const char* v = getenv("TTL_POOLED_LAST_LAYER"); pooled_last = v ? atoi(v) : 1; }
-            const bool compact_stats = pooled_last && (!c->text || n < 1024);   // the pooled-row forward stores them as [n]
+            static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
+            const bool compact_stats = pooled_last && n < 1024;   // the pooled-row forward stores them as [n]
             int stat_pitch = compact_stats ? 1 : T;
             if (pool) {
                 Prof p(c, 3, s);
@@ -1077,6 +1080,12 @@ int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t by
     std::string nm(name);
     bool tr = layer >= c->c.layer_lo && layer <= c->c.layer_hi;
     if (nm == "features") { src = c->feat; have = (size_t)c->saved_n * c->E * 4; }
+    // what the last ttl_episode* update really used: the confidence-selection list (int64, the reference's order:
+    // deyo.py:103-108 / ttl.py:50-54), its length (int32) and the per-view entropies (fp32)
+    // (capacity of the buffers: the adapted 1-view inference that ends an episode has reset saved_n to 1 by now)
+    else if (nm == "idx") { src = c->idx_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 8; }
+    else if (nm == "n_selected") { src = c->n_buf; have = 4; }
+    else if (nm == "entropy") { src = c->H_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 4; }
     else if (nm == "dh") { src = c->dh; have = M * D * 4; }
     else if (nm == "dqkv") { src = c->dqkv; have = M * c->ldwt * 2; }
     else if (!tr) return fail(TTL_EINVAL, "%s: layer %d is not a trained (saved) layer", name, layer);
@@ -1125,6 +1134,14 @@ int ttl_profile_read(ttl_ctx* c, double ms[TTL_NCLASS], long long launches[TTL_N
     c->gemm_flops = 0;
     c->gemm_bytes_last = c->gemm_bytes;
     c->gemm_bytes = 0;
+    c->gemm_flops_all_last = c->gemm_flops_all;
+    c->gemm_flops_all = 0;
+    return 0;
+}
+
+int ttl_profile_gemm_flops_all(ttl_ctx* c, double* flops) {
+    if (!c || !flops) return fail(TTL_EINVAL, "null argument");
+    *flops = c->gemm_flops_all_last;
     return 0;
 }
 

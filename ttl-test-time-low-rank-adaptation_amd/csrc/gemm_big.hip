@@ -42,14 +42,29 @@ constexpr int NTHR = 512;
 
 // NS slots of {one non-MFMA op, then its share of the NM MFMAs}; the first NV slots are VMEM (the DMA pieces:
 // requested as early as possible), the rest LDS reads
-template <int S, int NS, int NV, int NM>
+// Build-time schedule knobs (tools/gemm_big_ablate.sh NAME=VALUE builds variants for in-situ A/B):
+//   TTL_BIG_SCHED  0 = pinned interleave below, 1 = the compiler's own order
+//   TTL_BIG_MFIRST 1 = behind the barrier the MFMAs lead and the LDS reads follow (hipcc puts an lgkmcnt(0) in front of
+//                  the first MFMA after a barrier whatever it reads; with a read already issued that wait costs its latency)
+//   TTL_BIG_PRIO   1 = s_setprio 1 around the MFMA halves
+#ifndef TTL_BIG_SCHED
+#define TTL_BIG_SCHED 0
+#endif
+#ifndef TTL_BIG_MFIRST
+#define TTL_BIG_MFIRST 1
+#endif
+#ifndef TTL_BIG_PRIO
+#define TTL_BIG_PRIO 0
+#endif
+template <int S, int NS, int NV, int NM, bool MFIRST = false>
 struct Mix {
     static __device__ __forceinline__ void run() {
-        if constexpr (S < NS) {
-            __builtin_amdgcn_sched_group_barrier(S < NV ? 0x010 : 0x100, 1, 0);
+        if constexpr (TTL_BIG_SCHED == 0 && S < NS) {
             constexpr int m = NM / NS + (S < NM % NS ? 1 : 0);
-            if constexpr (m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
-            Mix<S + 1, NS, NV, NM>::run();
+            if constexpr (MFIRST && m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
+            __builtin_amdgcn_sched_group_barrier(S < NV ? 0x010 : 0x100, 1, 0);
+            if constexpr (!MFIRST && m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
+            Mix<S + 1, NS, NV, NM, MFIRST>::run();
         }
     }
 };
@@ -216,10 +231,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(wf[nt]));
             return;
         }
+        if (TTL_BIG_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+        if (TTL_BIG_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     int slot = blockIdx.x;
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             if constexpr (STAGES == 2) { issue_odd(kt + 2, cur); issue_uni(kt + 2, cur); }
             load_frags(nxt, 0, xf0, wf0);
             mma(xf1, wf1);
-            if constexpr (STAGES == 3) Mix<0, MT + 4, 0, 4 * MT>::run();
+            if constexpr (STAGES == 3) Mix<0, MT + 4, 0, 4 * MT, TTL_BIG_MFIRST != 0>::run();
             else Mix<0, NUNI + MT + 4, NUNI, 4 * MT>::run();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (STAGES == 3) { char* t = cur; cur = nxt; nxt = nn; nn = t; }

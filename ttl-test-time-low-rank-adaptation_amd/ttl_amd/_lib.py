@@ -86,6 +86,7 @@ SIGNATURES = {
     "ttl_profile_enable": (_I, [_P, _I]),
     "ttl_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "ttl_profile_gemm_bytes": (_I, [_P, C.POINTER(C.c_double)]),
+    "ttl_profile_gemm_flops_all": (_I, [_P, C.POINTER(C.c_double)]),
 }
 
 

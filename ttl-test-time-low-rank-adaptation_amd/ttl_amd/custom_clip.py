@@ -33,6 +33,7 @@ import torch.nn.init as init
 
 from . import synth
 from .config import get_config, get_text_config
+from ._lib import TtlError
 from .engine import TTLEngine, TextTowerEngine
 
 CLIP_WEIGHTS_ENV = "TTL_CLIP_WEIGHTS"   # local HF checkpoint dir of openai/clip-vit-base-patch16 (optional)
@@ -83,11 +84,18 @@ class _VitLogitsFn(torch.autograd.Function):
     def forward(ctx, owner, save, x, *params):
         ctx.owner = owner
         ctx.shapes = [p.shape for p in params]
-        return owner._engine_forward(x, save=save)
+        out, ctx.engine, ctx.generation = owner._engine_forward(x, save=save)
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
-        flat = ctx.owner.engine.backward(dlogits.contiguous())
+        # the activations of a saved forward live in ONE context's arena; never back-propagate through replaced ones
+        if ctx.generation is None or getattr(ctx.engine, "_pending_gen", None) != ctx.generation:
+            raise TtlError("backward through a forward whose saved activations were replaced by later forwards of the same "
+                           "model (two contexts hold at most two pending backwards; call backward earlier or run the "
+                           "other forwards under torch.no_grad())")
+        ctx.engine._pending_gen = None
+        flat = ctx.engine.backward(dlogits.contiguous())
         outs, off = [], 0
         for s in ctx.shapes:
             n = int(np.prod(s))
@@ -446,6 +454,7 @@ class ClipTestTimeTuning(nn.Module):
                 self.text_features = self.get_text_features()
             self.engine.set_text_features(self.text_features, float(self.logit_scale.exp()))
             self._text_dirty = False
+            self._text_version = getattr(self, "_text_version", 0) + 1    # the auxiliary context follows (see _aux_engine)
         return self.engine
 
     def _aux_engine(self):
@@ -465,6 +474,12 @@ class ClipTestTimeTuning(nn.Module):
             aux.set_text_features(self.text_features, float(self.logit_scale.exp()))
             aux.bind_lora(self._flat)
             self._aux, self._aux_flat_ptr = aux, self._flat.data_ptr()
+            self._aux_text_version = getattr(self, "_text_version", 0)
+        elif getattr(self, "_aux_text_version", None) != getattr(self, "_text_version", 0):
+            # reset_classnames() to another label set of the SAME size (ImageNet-A -> ImageNet-R: both 200) refreshed the
+            # main context's class embeddings only: the PLPD forward must score against the same classes
+            aux.set_text_features(self.text_features, float(self.logit_scale.exp()))
+            self._aux_text_version = getattr(self, "_text_version", 0)
         return aux
 
     def snapshot_flat(self):
@@ -476,11 +491,34 @@ class ClipTestTimeTuning(nn.Module):
             self._snap = torch.cat(parts).to(self._flat.device, torch.float32).contiguous()
         return self._snap
 
+    _saved_generation = 0        # bumped by every forward that saves activations for a backward
+
+    def _pick_context(self):
+        """The context a forward may overwrite: one that owes no backward; else the one whose saved forward is oldest.
+        The reference's own deyo.py runs a second grad-enabled model(x_prime) between model(x) and loss.backward()
+        (deyo.py:136): it lands in the auxiliary context and leaves the first forward's activations intact."""
+        main = self._ensure_engine()
+        if getattr(main, "_pending_gen", None) is None or self.lora_encoder == 'text':
+            return main                     # (text mode: one saving context; its PLPD forward has its own path below)
+        aux = self._aux_engine()
+        if getattr(aux, "_pending_gen", None) is None:
+            return aux
+        return main if main._pending_gen < aux._pending_gen else aux
+
     def _engine_forward(self, x, save):
-        eng = self._ensure_engine()
-        if x.shape[0] > eng.max_views:
-            raise ValueError(f"{x.shape[0]} views exceed the engine capacity {eng.max_views} (pass max_views=)")
-        return eng.forward(x, save=save)
+        """-> (logits, context used, generation of the saved activations or None)."""
+        main = self._ensure_engine()
+        if x.shape[0] > main.max_views:
+            raise ValueError(f"{x.shape[0]} views exceed the engine capacity {main.max_views} (pass max_views=)")
+        if self.lora_encoder == 'text' and not save and getattr(main, "_pending_gen", None) is not None:
+            return self._aux_engine().forward(x, save=False), None, None      # scores against the pending forward's text features
+        eng = self._pick_context()
+        gen = None
+        if save:
+            self._saved_generation += 1
+            gen = self._saved_generation
+        eng._pending_gen = gen               # whatever this context had saved is gone now
+        return eng.forward(x, save=bool(save)), eng, gen
 
     # ---- reference surface ------------------------------------------------------------------
     @property
@@ -489,6 +527,9 @@ class ClipTestTimeTuning(nn.Module):
 
     def LoRA_reset(self):
         self.LoRA_AB.reset()
+        for e in (self.engine, getattr(self, "_aux", None)):   # a new image: nothing is owed to the previous image's activations
+            if e is not None:
+                e._pending_gen = None
 
     def reset(self):
         self.prompt_learner.reset()

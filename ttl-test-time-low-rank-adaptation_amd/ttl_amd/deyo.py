@@ -72,6 +72,7 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
         return eng.forward(x, save=False)
     params, lr, betas, eps, wd = _adam_hparams(optimizer, model)
     step = _adam_state(optimizer, model, params)
+    eng._pending_gen = None          # (this path drives the context directly: nothing is owed to an autograd node)
     outputs = eng.forward(x, save=True)                                          # deyo.py:97
     mode = _lib.TTL_SEL_TOPK if getattr(args, "filter_ent", 0) else _lib.TTL_SEL_LE_THRESH
     reweight = float(getattr(args, "reweight_ent", 1))

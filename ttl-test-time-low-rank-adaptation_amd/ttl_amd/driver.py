@@ -22,6 +22,56 @@ def shard_indices(n_items, rank, world):
     return range(rank, n_items, world)
 
 
+class ImageShard:
+    """Which test images a rank runs, and the path's collectives.  ONE object used by bench.py,
+    ``eval.test_time_adapt_eval`` and ``evaluate_sharded``, so the world-size-2 gloo tests exercise the code the
+    GPU runs use.  Item ``i`` of a dataset belongs to rank ``i % world`` (ttl.py:321's loop, strided)."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        if not 0 <= rank < max(world, 1):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.rank, self.world, self.group = int(rank), max(int(world), 1), group
+
+    @classmethod
+    def from_env(cls, group=None):
+        rank, _, world = dist_env()
+        return cls(rank, world, group)
+
+    def owns(self, i):
+        return i % self.world == self.rank
+
+    def indices(self, n_items):
+        return shard_indices(n_items, self.rank, self.world)
+
+    def _reduce(self, t, op):
+        if self.world == 1:
+            return t
+        # gloo (CPU tests, 1-GPU smoke runs) reduces host tensors; nccl (= RCCL over xGMI) device tensors
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            c = t.cpu()
+            dist.all_reduce(c, op=op, group=self.group)
+            return c.to(t.device)
+        dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def sum(self, t):
+        """C1: all-reduce(SUM) of the [hits1, hits5, count] accumulator — the only collective of the path."""
+        return self._reduce(t, dist.ReduceOp.SUM)
+
+    def max(self, t):
+        return self._reduce(t, dist.ReduceOp.MAX)
+
+    def ranks_seen(self, device="cpu"):
+        """Number of ranks that really take part (all-reduce of ones): bench.py prints it next to n_gpus."""
+        return int(self.sum(torch.ones(1, dtype=torch.int64, device=device)).item())
+
+    def accuracy(self, acc):
+        """acc: int64 [hits1, hits5, count] of THIS rank -> dict identical on every rank."""
+        hits1, hits5, count = (int(v) for v in self.sum(acc).tolist())
+        return dict(hits1=hits1, hits5=hits5, count=count,
+                    top1=100.0 * hits1 / max(count, 1), top5=100.0 * hits5 / max(count, 1))
+
+
 def topk_hits(logits, target, ks=(1, 5)):
     """utils/tools.py:88-102 ``accuracy`` as integer hit counts (device tensors, no host sync)."""
     k = min(max(ks), logits.shape[1])
@@ -33,19 +83,16 @@ def topk_hits(logits, target, ks=(1, 5)):
 def evaluate_sharded(predict_fn, n_items, label_fn, rank=0, world=1, device="cpu", group=None):
     """predict_fn(i) -> logits [1,K] after adaptation on test item i; label_fn(i) -> int.
     Returns dict(top1, top5, count, hits1, hits5) — identical on every rank."""
+    shard = ImageShard(rank, world, group)
     acc = torch.zeros(3, dtype=torch.int64, device=device)      # [hits1, hits5, count]
-    for i in shard_indices(n_items, rank, world):
+    for i in shard.indices(n_items):
         logits = predict_fn(i)
         tgt = torch.tensor([label_fn(i)], device=logits.device)
         h1, h5 = topk_hits(logits, tgt)
         acc[0] += h1.to(acc.device)
         acc[1] += h5.to(acc.device)
         acc[2] += 1
-    if world > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # C1: the only collective of the path
-    hits1, hits5, count = (int(v) for v in acc.tolist())
-    return dict(hits1=hits1, hits5=hits5, count=count,
-                top1=100.0 * hits1 / max(count, 1), top5=100.0 * hits5 / max(count, 1))
+    return shard.accuracy(acc)
 
 
 class EpisodeRunner:
@@ -53,6 +100,9 @@ class EpisodeRunner:
     loss, LoRA backward, AdamW) -> adapted 1-view inference, as one enqueue (ttl_episode)."""
 
     def __init__(self, model, args):
+        if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
+            raise NotImplementedError("the fused episode has no PLPD stage: use ttl.test_time_tuning (step-wise path) for "
+                                      "--filter_plpd 1; reweight_plpd is commented out in the reference (deyo.py:176)")
         self.model = model
         self.args = args
         self.eng = model._ensure_engine()
@@ -168,6 +218,11 @@ class EpisodePipeline:
     def synchronize(self):
         for sl in self.slots:
             sl["stream"].synchronize()
+
+    def reset_totals(self):
+        self.synchronize()
+        for sl in self.slots:
+            sl["acc"].zero_()
 
     def totals(self):
         """Sum of the per-slot accuracy accumulators (device int64 [3]) after draining the streams."""

@@ -231,6 +231,13 @@ class TTLEngine:
         self._check(self.lib.ttl_debug_copy(self._h, name.encode(), int(layer), a.ctypes.data_as(C.c_void_p), a.nbytes))
         return a
 
+    def last_selection(self, n_views):
+        """(idx int64 [n], entropies fp32 [n_views]) the last fused update really used: the HIP selection list in the
+        reference's order (deyo.py:103-108 / ttl.py:50-54), read back from the context."""
+        n = int(self.debug_copy("n_selected", 0, (1,), np.int32)[0])
+        idx = self.debug_copy("idx", 0, (n_views,), np.int64)[:n]
+        return idx, self.debug_copy("entropy", 0, (n_views,), np.float32)
+
     def profile_enable(self, on=True):
         self._check(self.lib.ttl_profile_enable(self._h, 1 if on else 0))
 
@@ -242,6 +249,8 @@ class TTLEngine:
         by = C.c_double()
         self._check(self.lib.ttl_profile_gemm_bytes(self._h, C.byref(by)))
         self.last_gemm_bytes = by.value
+        self._check(self.lib.ttl_profile_gemm_flops_all(self._h, C.byref(by)))
+        self.last_gemm_flops_all = by.value
         return ({k: ms[i] for i, k in enumerate(_lib.PROFILE_CLASSES)},
                 {k: cnt[i] for i, k in enumerate(_lib.PROFILE_CLASSES)}, fl.value)
 

@@ -21,11 +21,16 @@ import torch
 import torch.distributed as dist
 
 from . import synth
-from .driver import EpisodePipeline, dist_env
+from .driver import EpisodePipeline, ImageShard, dist_env
 
 
 def episode_kwargs_from_args(args):
-    """Reference CLI semantics -> fused-episode arguments (incl. tta_steps**2 on the DeYO branch, Q6)."""
+    """Reference CLI semantics -> fused-episode arguments (incl. tta_steps**2 on the DeYO branch, Q6).  The fused
+    ttl_episode has no PLPD stage: callers route ``--filter_plpd 1`` to the step-wise host loop instead."""
+    if getattr(args, "reweight_plpd", 0):
+        raise NotImplementedError("reweight_plpd: the term is commented out in the reference (deyo.py:176)")
+    if getattr(args, "filter_plpd", 0):
+        raise NotImplementedError("filter_plpd needs the step-wise path (ttl.test_time_tuning): the fused episode has no PLPD stage")
     deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
     return dict(n_updates=(args.tta_steps ** 2 if deyo else args.tta_steps), objective="deyo" if deyo else "tpt",
                 mode=1 if getattr(args, "filter_ent", 0) else 0, rho=args.selection_p, margin=args.deyo_margin_e0,
@@ -44,6 +49,11 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
     from .deyo import _adam_hparams
     model.eval()
     eng = model._ensure_engine()
+    if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
+        # --filter_plpd 1 (deyo.py:115-151): the second forward on destroyed views and the host-side keep mask sit between
+        # forward and backward, so these runs take the reference-shaped per-image loop (ttl.py:338-352) on the step-wise
+        # entry points instead of being silently evaluated as plain DeYO
+        return _host_loop_eval(val_loader, model, optimizer, optim_state, scaler, args, rank, world, gpu_augmenter)
     _, lr, betas, eps, wd = _adam_hparams(optimizer, model)
     kw = episode_kwargs_from_args(args)
     kw.update(lr=lr, betas=betas, eps=eps, weight_decay=wd)
@@ -75,11 +85,12 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
                                             eng.device, n_streams=n_streams, max_views=eng.max_views,
                                             precision=model.precision, engine_factory=factory, n_classes=n_cls)
     dev = eng.device
+    shard = ImageShard(rank, world)
     for i, (images, target) in enumerate(val_loader):
-        if i % world != rank:
+        if not shard.owns(i):
             continue
         if gpu_augmenter is not None and torch.is_tensor(images) and images.dtype == torch.uint8:
-            images = gpu_augmenter(images.to(dev, non_blocking=True))                       # datautils.py:141-157 on the GPU
+            images = gpu_augmenter(images.to(dev, non_blocking=True), i)                    # datautils.py:141-157 on the GPU
         elif isinstance(images, (list, tuple)):
             images = torch.cat([im.to(dev, non_blocking=True) for im in images], dim=0)     # ttl.py:324-336
         else:
@@ -88,14 +99,46 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
                 images = images.squeeze(0)
         tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev)
         pipe.submit(images, target=tgt, **kw)
-    acc = pipe.totals()
-    if world > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-    h1, h5, cnt = (int(v) for v in acc.tolist())
-    return [100.0 * h1 / max(cnt, 1), 100.0 * h5 / max(cnt, 1)]
+    r = shard.accuracy(pipe.totals())
+    return [r["top1"], r["top5"]]
 
 
 test_time_adapt_eval.__test__ = False  # not a pytest test
+
+
+def _host_loop_eval(val_loader, model, optimizer, optim_state, scaler, args, rank, world, gpu_augmenter):
+    """ttl.py:321-356 image by image on the step-wise HIP entry points (forward / loss / backward / AdamW)."""
+    import copy
+    from .driver import topk_hits
+    from .ttl import test_time_tuning
+    dev = model._ensure_engine().device
+    shard = ImageShard(rank, world)
+    if optim_state is None:
+        optim_state = copy.deepcopy(optimizer.state_dict())
+    acc = torch.zeros(3, dtype=torch.int64, device=dev)
+    for i, (images, target) in enumerate(val_loader):
+        if not shard.owns(i):
+            continue
+        if gpu_augmenter is not None and torch.is_tensor(images) and images.dtype == torch.uint8:
+            images = gpu_augmenter(images.to(dev, non_blocking=True), i)
+        elif isinstance(images, (list, tuple)):
+            images = torch.cat([im.to(dev, non_blocking=True) for im in images], dim=0)
+        else:
+            images = images.to(dev, non_blocking=True)
+            if images.dim() == 5:
+                images = images.squeeze(0)
+        with torch.no_grad():
+            model.LoRA_reset()                                                    # ttl.py:341-343
+        optimizer.load_state_dict(optim_state)                                    # ttl.py:344
+        test_time_tuning(model, images, optimizer, scaler, args)                  # ttl.py:347
+        with torch.no_grad():
+            out = model(images[:1])                                               # ttl.py:350-352
+        h1, h5 = topk_hits(out, torch.as_tensor(target).reshape(-1)[:1].to(dev))
+        acc[0] += h1
+        acc[1] += h5
+        acc[2] += 1
+    r = shard.accuracy(acc)
+    return [r["top1"], r["top5"]]
 
 
 def _split(flat, like):
@@ -174,7 +217,7 @@ def main():
     if a.gpu_views:
         from .views import GpuAugMixAugmenter
         data = SyntheticImages(a.images, a.classes)
-        aug = GpuAugMixAugmenter(a.views - 1, model.cfg.image_size, precision=a.precision)
+        aug = GpuAugMixAugmenter(a.views - 1, model.cfg.image_size, precision=a.precision, seed=0)
     else:
         data = SyntheticViews(model.cfg, a.images, a.views, a.classes)
     # untimed first pass: builds the per-stream contexts (weight images, arenas), like loading the model

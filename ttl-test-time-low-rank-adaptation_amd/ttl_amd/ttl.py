@@ -45,6 +45,7 @@ def test_time_tuning(model, inputs, optimizer, scaler, args):
     sel = None
     for j in range(args.tta_steps):
         step = _adam_state(optimizer, model, params)
+        eng._pending_gen = None
         out = eng.forward(inputs, save=True)
         sel = eng.tpt_select_loss(out, rho=args.selection_p, idx=None if sel is None else sel["idx"],
                                   n=None if sel is None else sel["n"])

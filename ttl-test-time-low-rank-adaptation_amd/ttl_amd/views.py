@@ -90,14 +90,29 @@ def make_views(image_u8_hwc, boxes, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=
     return out
 
 
+def item_generator(seed, index):
+    """The RNG of test item ``index``: a function of (seed, GLOBAL index) only, so the crop boxes an image gets do
+    not depend on how many ranks share the dataset or on which rank runs it.  The reference draws from
+    one global stream in dataset order (data/datautils.py:141-157 under ttl.py:321); that order is not reproducible
+    once images are sharded, an index-keyed stream is."""
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 0x9E3779B1 + int(index) * 0x85EBCA77 + 0x165667B1) % (1 << 63))
+    return g
+
+
 class GpuAugMixAugmenter:
     """Callable with the reference augmenter's role (data/datautils.py:141-157) for decoded images:
-    ``views = aug(image_u8_hwc)`` -> [n_views,3,S,S] on the GPU (view 0 = the un-augmented view)."""
+    ``views = aug(image_u8_hwc, index)`` -> [n_views,3,S,S] on the GPU (view 0 = the un-augmented view).
+    With ``seed`` set, item ``index`` draws its boxes from ``item_generator(seed, index)`` (world-size invariant);
+    without, from ``generator`` / the global torch RNG in call order like the reference's host pipeline."""
 
-    def __init__(self, n_views=63, size=224, generator=None, precision="bf16"):
-        self.n_views, self.size, self.generator, self.precision = n_views, size, generator, precision
+    def __init__(self, n_views=63, size=224, generator=None, precision="bf16", seed=None):
+        self.n_views, self.size, self.generator, self.precision, self.seed = n_views, size, generator, precision, seed
 
-    def __call__(self, image_u8_hwc):
+    def boxes(self, height, width, index=None):
+        g = item_generator(self.seed, index) if (self.seed is not None and index is not None) else self.generator
+        return draw_boxes(height, width, self.n_views + 1, g)
+
+    def __call__(self, image_u8_hwc, index=None):
         H, W = int(image_u8_hwc.shape[0]), int(image_u8_hwc.shape[1])
-        boxes = draw_boxes(H, W, self.n_views + 1, self.generator)
-        return make_views(image_u8_hwc, boxes, self.size, precision=self.precision)
+        return make_views(image_u8_hwc, self.boxes(H, W, index), self.size, precision=self.precision)
