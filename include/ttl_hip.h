@@ -130,10 +130,30 @@ int ttl_vit_backward_lora(ttl_ctx* ctx, const float* dlogits, int n_views, void*
 /* torch.optim.AdamW.step over one flat buffer (ttl.py:218; deyo.py:187).  `step` is the 1-based
  * step count of this update.  If `n_selected` (device int32, may be NULL) is 0 the update is
  * skipped (deyo.py:183: `if final_backward != 0`); a non-finite gradient element also skips
- * that element's update (GradScaler's skip-on-inf, deyo.py:187, per element). */
+ * that element's update.  Context-free primitive; the reference's GradScaler contract (whole step or
+ * nothing, dynamic scale) is ttl_optimizer_step below, which ttl_episode and the host surface use. */
 int ttl_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    const int* n_selected, void* stream);
+
+/* ---- torch.amp.GradScaler semantics (ttl.py:222 `GradScaler(init_scale=1000)`, deyo.py:186-188 / ttl.py:106-108
+ * `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`), state on the device per context:
+ * the backward runs on scale * loss, the gradient reduction unscales and records any inf/nan, and then the WHOLE
+ * optimizer step is skipped and the scale multiplied by backoff_factor, or the step is taken and the scale multiplied
+ * by growth_factor after growth_interval consecutive clean steps.  The scale is the only state that survives from one
+ * test image to the next.  Defaults: fp16-operand build dynamic from 2^10; bf16 build scale 1, not
+ * dynamic (bf16 has fp32's exponent range) — the whole-step skip on non-finite gradients applies to both. */
+int ttl_scaler_config(ttl_ctx* ctx, int dynamic, float init_scale, float growth_factor, float backoff_factor, int growth_interval);
+/* Synchronises.  Any output may be NULL.  optimizer_steps = steps really taken since the last episodic reset. */
+int ttl_scaler_state(ttl_ctx* ctx, float* scale, int* growth_tracker, int* skipped_steps, int* optimizer_steps);
+/* scaler.unscale_(optimizer) for gradients produced outside ttl_vit_backward_lora (which unscales by itself). */
+int ttl_scaler_unscale(ttl_ctx* ctx, float* grads, size_t n, void* stream);
+/* scaler.step(optimizer) + scaler.update(): ttl_adamw_step with the context's GradScaler decision — all of the step
+ * or none of it.  step >= 1: the 1-based count to use for the bias corrections if the step is taken; 0: the context
+ * counts taken steps itself (reset by ttl_episode / ttl_lora_reset is NOT implied: see ttl_scaler_state). */
+int ttl_optimizer_step(ttl_ctx* ctx, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       const int* n_selected, void* stream);
 
 /* Episodic reset: LoRA_AB.reset() (clip/custom_clip.py:202-215) + optimizer.load_state_dict of the
  * empty state (ttl.py:344): params <- snapshot, exp_avg = exp_avg_sq = 0.  m/v may be NULL. */

@@ -214,3 +214,63 @@ def test_adamw_vs_torch_reference(lib, unit):
     chk(lib, lib.ttl_lora_reset(P(p), P(snap), P(m), P(v), p.numel(), S()))
     torch.cuda.synchronize()
     assert torch.equal(p, snap) and not m.any() and not v.any()
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(12608, 2304, 832), (12608, 768, 3072), (12608, 3072, 768), (2056, 1024, 1024), (1500, 256, 192),
+                                   (16448, 1024, 4096)])
+def test_gemm_big_tiles_with_fused_epilogues(lib, M, N, K, epi):
+    """The big-M kernel of gemm_big.hip (160x256x64 tiles, persistent blocks, 3-stage DMA ring, bias / residual folded into
+    the accumulator init) through ttl_gemm_nt_epi: every epilogue the episode uses, row counts that end inside the last
+    row tile, one / several tiles per block, odd K-tile counts — against an fp32 matmul of the same bf16 operands."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Mp = (M + 1279) // 1280 * 1280
+    res = torch.randn(Mp, N, generator=g).cuda() if epi == 2 else None
+    c = torch.full((Mp, N), 7.0, device="cuda", dtype=torch.float32 if epi in (0, 2) else torch.bfloat16)
+    chk(lib, lib.ttl_gemm_nt_epi(P(a), K, P(b), K, P(c), N, M, N, K, epi, P(bias), P(res) if res is not None else None, N, Mp, S()))
+    torch.cuda.synchronize()
+    want = a.float() @ b.float().t() + bias
+    if epi == 2:
+        want = want + res[:M]
+    if epi == 3:
+        want = want * torch.sigmoid(1.702 * want)
+    got = c[:M].float()
+    tol = 2e-5 if epi in (0, 2) else 6e-3        # fp32 out: accumulation order only; operand-dtype out: one bf16 rounding
+    assert max_rel(got.cpu().numpy(), want.cpu().numpy()) < tol
+    # rows of the arena padding beyond round_up(M, 160) are never written
+    top = (M + 159) // 160 * 160
+    if top < Mp:
+        assert (c[top:].float() == 7.0).all()
+
+
+def test_gradscaler_known_answers(lib):
+    """ttl_scaler_config / ttl_scaler_unscale / ttl_optimizer_step against the reference's own objects — torch.amp.GradScaler(
+    init_scale=1000) around torch.optim.AdamW — over 9 updates with an inf and a nan injected (fixture written by
+    tests/golden/make_gradscaler_golden.py): the WHOLE step is skipped on a non-finite gradient (params, exp_avg, exp_avg_sq
+    and the Adam step count untouched), the scale halves, and doubles again after growth_interval clean steps."""
+    import os
+    from conftest import GOLDEN
+    from ttl_amd.config import get_config
+    from ttl_amd.engine import TTLEngine
+    u = np.load(os.path.join(GOLDEN, "unit_gradscaler.npz"))
+    eng = TTLEngine(get_config("tiny"), 4, 10, "cuda:0")
+    eng.scaler_config(True, float(u["init_scale"]), float(u["growth_factor"]), float(u["backoff_factor"]), int(u["growth_interval"]))
+    p = torch.from_numpy(u["p0"]).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = float(u["lr"])
+    for t in range(u["grads"].shape[0]):
+        scale = eng.scaler_state()["scale"]
+        g = (torch.from_numpy(u["grads"][t]) * scale).cuda()       # what a backward of scale * loss leaves behind
+        eng.scaler_unscale(g)                                       # scaler.unscale_ (+ found_inf)
+        eng.optimizer_step(p, g, m, v, 0, lr=lr)                    # scaler.step + scaler.update (step counted on the device)
+        st = eng.scaler_state()
+        assert st["scale"] == float(u["scale"][t]), (t, st, u["scale"][t])
+        assert st["optimizer_steps"] == int(u["step"][t]), (t, st, u["step"][t])
+        np.testing.assert_allclose(p.cpu().numpy(), u["params"][t], rtol=2e-6, atol=2e-8, err_msg=f"params after update {t + 1}")
+        np.testing.assert_allclose(m.cpu().numpy(), u["m"][t], rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(v.cpu().numpy(), u["v"][t], rtol=2e-5, atol=1e-12)
+    assert eng.scaler_state()["skipped_steps"] == 2
+    eng.close()

@@ -107,6 +107,9 @@ struct ttl_ctx {
     float* wg_partial;
     float* gemm_ws; size_t gemm_ws_bytes;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
+    // GradScaler state (device) and policy (host): ttl.py:222, deyo.py:186-188
+    ScalerState sc{nullptr, nullptr};
+    int sc_dynamic = 0; float sc_growth = 2.f, sc_backoff = 0.5f; int sc_interval = 2000;
     bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
     bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_flops_all = 0, gemm_flops_all_last = 0, gemm_bytes = 0, gemm_bytes_last = 0;
@@ -298,6 +301,13 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     const size_t nmax = N > (size_t)k->max_classes ? N : (size_t)k->max_classes;
     ALLOC(c->loss_scratch, 7 * nmax + 16, true);
     ALLOC(c->idx_buf, nmax, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, nmax, true);
+    ALLOC(c->sc.f, SC_NF, true); ALLOC(c->sc.i, SC_NI, true);
+    {   // fp16-operand build: dynamic loss scaling from 2^10 like the reference's GradScaler(init_scale=1000) (ttl.py:222);
+        // bf16 needs no loss scale (scale 1, fixed) but keeps the whole-step skip on non-finite gradients
+        const float init[SC_NF] = {TTL_GRAD_SCALE, 1.0f / TTL_GRAD_SCALE, 1.f, 1.f};
+        HIP_TRY(hipMemcpy(c->sc.f, init, sizeof init, hipMemcpyHostToDevice));
+        c->sc_dynamic = (TTL_GRAD_SCALE != 1.0f);
+    }
     guard.ok = true;
     *out = c;
     return 0;
@@ -502,6 +512,7 @@ static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* l
     a.WpT = c->wpT; a.Wp = c->wp; a.tfeat = c->tfeat; a.tfeatT = c->tfeatT; a.scale = c->scale;
     a.cls_mean = c->cls_mean; a.cls_rstd = c->cls_rstd; a.y = c->ycls; a.f = c->feat; a.logits = logits; a.feats_out = feats_out;
     a.tmp_e = c->head_te; a.tmp_d = c->head_td;
+    a.gscale = c->sc.f;
     return a;
 }
 
@@ -745,6 +756,7 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
     const int causal = c->text;
     const int* pool = c->text ? c->pool : nullptr;
     int rc;
+    HIP_TRY(hipMemsetAsync(c->sc.i + SC_FOUND_INF, 0, sizeof(int), s));   // found_inf describes THIS backward's gradients
     float* dh = c->dh;      // gradient w.r.t. the residual stream at the current depth
     float* dh_alt = c->dh2;
     {
@@ -846,7 +858,8 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             Prof p(c, 4, s);
             HIP_TRY(launch_lora_skinny(c->dqkv, c->ldwt, 0, 2 * D, l.btcat, D, r, c->scaling, c->dqkv + 3 * D, c->ldwt, M, s));
             float* g = c->lora_g + (size_t)(i - c->c.layer_lo) * 4 * per;
-            HIP_TRY(launch_lora_wgrad(l.x1ext, c->ldx, c->dqkv, c->ldwt, M, D, r, c->wg_partial, g, g + per, g + 2 * per, g + 3 * per, s));
+            HIP_TRY(launch_lora_wgrad(l.x1ext, c->ldx, c->dqkv, c->ldwt, M, D, r, c->wg_partial, g, g + per, g + 2 * per, g + 3 * per, s,
+                                      c->sc.f, c->sc.i));
         }
         if (first) break;
         // ---- dx1 = [dq dk dv | dU]·[Wqkv | A]  ; dh_in = dh_mid + LN1^T(dx1)
@@ -889,6 +902,48 @@ int ttl_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float
     return 0;
 }
 
+int ttl_scaler_config(ttl_ctx* c, int dynamic, float init_scale, float growth_factor, float backoff_factor, int growth_interval) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    if (!(init_scale > 0.f) || !(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f) || growth_interval < 1)
+        return fail(TTL_EINVAL, "bad GradScaler parameters");
+    HIP_TRY(hipDeviceSynchronize());
+    const float f[SC_NF] = {init_scale, 1.0f / init_scale, 1.f, 1.f};
+    const int z[SC_NI] = {0};
+    HIP_TRY(hipMemcpy(c->sc.f, f, sizeof f, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->sc.i, z, sizeof z, hipMemcpyHostToDevice));
+    c->sc_dynamic = dynamic != 0; c->sc_growth = growth_factor; c->sc_backoff = backoff_factor; c->sc_interval = growth_interval;
+    return 0;
+}
+
+int ttl_scaler_state(ttl_ctx* c, float* scale, int* growth_tracker, int* skipped_steps, int* optimizer_steps) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    HIP_TRY(hipDeviceSynchronize());
+    float f[SC_NF]; int i[SC_NI];
+    HIP_TRY(hipMemcpy(f, c->sc.f, sizeof f, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(i, c->sc.i, sizeof i, hipMemcpyDeviceToHost));
+    if (scale) *scale = f[SC_SCALE];
+    if (growth_tracker) *growth_tracker = i[SC_TRACKER];
+    if (skipped_steps) *skipped_steps = i[SC_SKIPPED];
+    if (optimizer_steps) *optimizer_steps = i[SC_STEP];
+    return 0;
+}
+
+int ttl_scaler_unscale(ttl_ctx* c, float* grads, size_t n, void* stream) {
+    if (!c || !grads) return fail(TTL_EINVAL, "null argument");
+    HIP_TRY(launch_scaler_unscale(grads, n, c->sc, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_optimizer_step(ttl_ctx* c, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                       float wd, int step, const int* nsel, void* stream) {
+    if (!c || !p || !g || !m || !v) return fail(TTL_EINVAL, "null argument");
+    if (step < 0) return fail(TTL_EINVAL, "step must be >= 1 (or 0: count on the device)");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_scaler_pre_step(c->sc, nsel, step, b1, b2, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s));
+    HIP_TRY(launch_adamw_dev(p, g, m, v, n, lr, b1, b2, eps, wd, c->sc, s));
+    return 0;
+}
+
 int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, void* stream) {
     if (!p || !snap) return fail(TTL_EINVAL, "null argument");
     HIP_TRY(launch_lora_reset(p, snap, m, v, n, (hipStream_t)stream));
@@ -902,6 +957,7 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc;
     HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
+    HIP_TRY(launch_scaler_reset_step(c->sc, s));   // optimizer.load_state_dict(empty): step count 0; the loss scale PERSISTS (Q14)
     for (int u = 0; u < a->n_updates; ++u) {
         if ((rc = forward_impl(c, a->x, a->n_views, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr,
                                stream)))
@@ -914,9 +970,11 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
         }
         if ((rc = backward_impl(c, c->dlogits, a->n_views, stream))) return rc;
         {
-            Prof p(c, 5, s);
-            HIP_TRY(launch_adamw(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                 a->weight_decay, u + 1, c->n_buf, s));
+            Prof p(c, 5, s);   // scaler.step(optimizer); scaler.update()  (deyo.py:186-188): whole step or nothing
+            HIP_TRY(launch_scaler_pre_step(c->sc, c->n_buf, 0, a->beta1, a->beta2, c->sc_dynamic, c->sc_growth, c->sc_backoff,
+                                           c->sc_interval, s));
+            HIP_TRY(launch_adamw_dev(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                     a->weight_decay, c->sc, s));
         }
     }
     if (a->n_updates < 1) return ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
@@ -978,6 +1036,7 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     hipStream_t s = (hipStream_t)stream;
     int rc;
     HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
+    HIP_TRY(launch_scaler_reset_step(c->sc, s));
     // image side: forward only; its own logits (against whatever peer features it holds) are not used
     float* feats = v->head_te;   // [max_views, E] scratch of the image context
     if ((rc = forward_impl(v, a->x, a->n_views, 0, 0, nullptr, feats, stream))) return rc;
@@ -996,8 +1055,10 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
         if ((rc = backward_impl(c, c->dlogits_kn, K, stream))) return rc;
         {
             Prof p(c, 5, s);
-            HIP_TRY(launch_adamw(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                 a->weight_decay, u + 1, c->n_buf, s));
+            HIP_TRY(launch_scaler_pre_step(c->sc, c->n_buf, 0, a->beta1, a->beta2, c->sc_dynamic, c->sc_growth, c->sc_backoff,
+                                           c->sc_interval, s));
+            HIP_TRY(launch_adamw_dev(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                     a->weight_decay, c->sc, s));
         }
     }
     // adapted prediction on view 0: new text features (layers below layer_lo unchanged -> resume), row 0 of the logits

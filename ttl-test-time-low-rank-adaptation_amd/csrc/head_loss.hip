@@ -94,8 +94,9 @@ __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* _
     for (int k = threadIdx.x; k < a.K; k += HB) sm[k] = dz[(size_t)v * a.K + k];
     __syncthreads();
     const float acc = matvec64(sm, a.tfeat, a.K, a.E, e, slice, part, 0);
-    // TTL_GRAD_SCALE: fixed loss scale of the fp16 build (1 for bf16), removed again in wgrad_reduce_kernel
-    if (slice == 0 && e < a.E) a.tmp_e[(size_t)v * a.E + e] = acc * a.scale * TTL_GRAD_SCALE;
+    // scaler.scale(loss): the loss scale of the context's GradScaler state (1 in the bf16 build), removed again in
+    // wgrad_reduce_kernel (scaler.unscale_)
+    if (slice == 0 && e < a.E) a.tmp_e[(size_t)v * a.E + e] = acc * a.scale * (a.gscale ? a.gscale[0] : 1.0f);
 }
 // grid (ceil(D/64), n): df = (dfh - fh <fh,dfh>)/||f|| ; dy[v][d] = sum_e df[e] Wp[e][d]
 __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
@@ -299,6 +300,52 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     v[i] = vi;
 }
 
+__global__ void scaler_pre_step_kernel(ScalerState st, const int* __restrict__ nsel, int host_step, float b1, float b2, int dynamic,
+                                       float growth, float backoff, int interval) {
+    if (nsel && *nsel == 0) { st.i[SC_DO_STEP] = 0; st.i[SC_FOUND_INF] = 0; return; }   // deyo.py:183: neither step nor update
+    if (st.i[SC_FOUND_INF]) {
+        st.i[SC_DO_STEP] = 0;
+        st.i[SC_SKIPPED] += 1;
+        st.i[SC_TRACKER] = 0;
+        if (dynamic) st.f[SC_SCALE] *= backoff;
+    } else {
+        const int t = host_step > 0 ? host_step : st.i[SC_STEP] + 1;
+        st.i[SC_STEP] = t;
+        st.i[SC_DO_STEP] = 1;
+        st.f[SC_BC1] = (float)(1.0 - pow((double)b1, (double)t));
+        st.f[SC_BC2S] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+        if (dynamic && ++st.i[SC_TRACKER] >= interval) { st.f[SC_SCALE] *= growth; st.i[SC_TRACKER] = 0; }
+    }
+    st.f[SC_INV] = 1.0f / st.f[SC_SCALE];
+    st.i[SC_FOUND_INF] = 0;
+}
+
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 size_t n, float lr, float b1, float b2, float eps, float wd, ScalerState st) {
+    if (!st.i[SC_DO_STEP]) return;       // the whole step or nothing (GradScaler.step)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float bc1 = st.f[SC_BC1], bc2_sqrt = st.f[SC_BC2S];
+    float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    float mi = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ void scaler_unscale_kernel(float* __restrict__ g, size_t n, ScalerState st) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = g[i] * st.f[SC_INV];
+    g[i] = t;
+    if (!isfinite(t)) atomicOr(st.i + SC_FOUND_INF, 1);
+}
+
+__global__ void scaler_reset_step_kernel(ScalerState st) { st.i[SC_STEP] = 0; st.i[SC_DO_STEP] = 0; st.i[SC_FOUND_INF] = 0; }
+
 __global__ void reset_kernel(float* __restrict__ p, const float* __restrict__ snap, float* __restrict__ m,
                              float* __restrict__ v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,6 +405,28 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
     double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
                        wd, (float)bc1, (float)sqrt(bc2), n_selected);
+    return hipGetLastError();
+}
+
+hipError_t launch_scaler_pre_step(ScalerState st, const int* n_selected, int host_step, float b1, float b2, int dynamic, float growth,
+                                  float backoff, int interval, hipStream_t s) {
+    hipLaunchKernelGGL(scaler_pre_step_kernel, dim3(1), dim3(1), 0, s, st, n_selected, host_step, b1, b2, dynamic, growth, backoff, interval);
+    return hipGetLastError();
+}
+
+hipError_t launch_adamw_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                            ScalerState st, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_scaler_unscale(float* g, size_t n, ScalerState st, hipStream_t s) {
+    hipLaunchKernelGGL(scaler_unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, n, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_scaler_reset_step(ScalerState st, hipStream_t s) {
+    hipLaunchKernelGGL(scaler_reset_step_kernel, dim3(1), dim3(1), 0, s, st);
     return hipGetLastError();
 }
 

@@ -106,6 +106,7 @@ struct HeadArgs {
     const float* tfeat;    // [K][E]
     const float* tfeatT;   // [E][K]
     float scale;           // exp(logit_scale)
+    const float* gscale;   // device: loss scale of the backward (ScalerState.f[0]); null = 1
     float* cls_mean; float* cls_rstd; float* y; float* f; // saves [n],[n],[n,D],[n,E]
     float* logits;         // [n,K]
     float* feats_out;      // optional [n,E]
@@ -122,6 +123,24 @@ hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective,
                                hipStream_t s, const unsigned char* keep = nullptr);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                         float eps, float wd, int step, const int* n_selected, hipStream_t s);
+// ---- torch.amp.GradScaler semantics (ttl.py:222, deyo.py:186-188) with the state on the device, so that a whole
+// episode stays one enqueue.  f[0] loss scale, f[1] 1/scale, f[2] bias correction 1 - b1^t, f[3] sqrt(1 - b2^t);
+// i[0] found_inf (OR-ed by the gradient reduction), i[1] growth tracker, i[2] optimizer steps taken since the reset,
+// i[3] do_step (decision of the current update), i[4] steps skipped on inf/nan so far.
+struct ScalerState { float* f; int* i; };
+enum { SC_SCALE = 0, SC_INV = 1, SC_BC1 = 2, SC_BC2S = 3, SC_NF = 4 };
+enum { SC_FOUND_INF = 0, SC_TRACKER = 1, SC_STEP = 2, SC_DO_STEP = 3, SC_SKIPPED = 4, SC_NI = 8 };
+// scaler.step + scaler.update decision of one update (one thread): nothing at all when *n_selected == 0 (deyo.py:183);
+// found_inf -> skip the WHOLE step, scale *= backoff, tracker = 0; else step (host_step > 0: that step count, else the
+// device counter + 1), tracker += 1, scale *= growth every `interval` clean steps.  Clears found_inf.
+hipError_t launch_scaler_pre_step(ScalerState st, const int* n_selected, int host_step, float b1, float b2, int dynamic,
+                                  float growth, float backoff, int interval, hipStream_t s);
+// AdamW over the flat buffer iff i[SC_DO_STEP], bias corrections from f[]
+hipError_t launch_adamw_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                            float wd, ScalerState st, hipStream_t s);
+// scaler.unscale_(optimizer) on an arbitrary gradient buffer: g *= 1/scale, found_inf |= any non-finite
+hipError_t launch_scaler_unscale(float* g, size_t n, ScalerState st, hipStream_t s);
+hipError_t launch_scaler_reset_step(ScalerState st, hipStream_t s);
 hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- LoRA (lora.hip)
@@ -140,8 +159,11 @@ hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, co
 //   dB_q = dq^T Us_q, dB_v = dv^T Us_v, dA_q = dU_q^T x1, dA_v = dU_v^T x1      (Us = s*x1*A^T)
 // x1ext [M][ldx]: cols 0..D = x1, cols D..D+2r = Us ; dqkv [M][ldd]: dq | dk | dv | dU_q dU_v
 // partial: fp32 scratch [nchunk][4][r][D]; grads written to gAq [r,D], gBq [D,r], gAv, gBv
+// scaler_f / scaler_i (ScalerState arrays, may be null): the gradients are divided by the loss scale scaler_f[0] and
+// any non-finite value sets scaler_i[0] (found_inf)
 hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r,
-                             float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s);
+                             float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s,
+                             const float* scaler_f = nullptr, int* scaler_i = nullptr);
 int lora_wgrad_chunks(int M);
 
 // ---------------------------------------------------------------- view generator (views.hip)

@@ -9,6 +9,8 @@
 //   lora_wgrad   : dA = dU^T x1, dB = dy^T (s·U): reductions over all M = N·T tokens, done as
 //                  chunked MFMA products (both operands k-strided -> ds_read_b64_tr_b16) plus a
 //                  deterministic second-pass sum (no float atomics: bitwise reproducible grads)
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace {
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const op_t* __restrict__ x1e
 // fixed order -> deterministic; one thread walking all ~50 chunks serially left the 9.8 MB read latency-bound (16 us)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, int D, int r,
                                                            float* __restrict__ gAq, float* __restrict__ gBq,
-                                                           float* __restrict__ gAv, float* __restrict__ gBv) {
+                                                           float* __restrict__ gAv, float* __restrict__ gBv,
+                                                           const float* __restrict__ scaler_f, int* __restrict__ scaler_i) {
     __shared__ float part[4][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     const int prod = blockIdx.y;
@@ -180,7 +183,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (slice != 0 || i >= r * D) return;
     float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    s *= (1.0f / TTL_GRAD_SCALE);   // undo the backward's loss scale (fp16 build; 1 for bf16)
+    // scaler.unscale_: undo the backward's loss scale; any inf/nan makes the optimizer skip the WHOLE step (deyo.py:186-188)
+    if (scaler_f) s *= scaler_f[1];
+    if (scaler_i && !isfinite(s)) atomicOr(scaler_i, 1);
     int j = i / D, d = i - j * D;
     if (prod == 0) gBq[(size_t)d * r + j] = s;
     else if (prod == 1) gBv[(size_t)d * r + j] = s;
@@ -228,21 +233,21 @@ hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, co
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
 
 hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r, float* partial,
-                             float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s) {
+                             float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s, const float* scaler_f, int* scaler_i) {
     if (D % WG_BN) return hipErrorInvalidValue;
     const int nch = lora_wgrad_chunks(M);
     dim3 grid(nch, D / WG_BN, 4);
     if (r == 16) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 16 * 2;
-        static bool done = false;
-        if (!done) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done = true; }
+        static std::atomic<bool> done{false};
+        if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
         hipLaunchKernelGGL((wgrad_kernel<16>), grid, dim3(256), SMEM, s, x1ext, ldx, dqkv, ldd, M, D, partial, nch);
     } else if (r == 32) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 32 * 2;
-        static bool done = false;
-        if (!done) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done = true; }
+        static std::atomic<bool> done{false};
+        if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
         hipLaunchKernelGGL((wgrad_kernel<32>), grid, dim3(256), SMEM, s, x1ext, ldx, dqkv, ldd, M, D, partial, nch);
     } else return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, 4), dim3(256), 0, s, partial, nch, D, r, gAq, gBq, gAv, gBv);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, 4), dim3(256), 0, s, partial, nch, D, r, gAq, gBq, gAv, gBv, scaler_f, scaler_i);
     return hipGetLastError();
 }

@@ -64,6 +64,10 @@ SIGNATURES = {
     "ttl_vit_backward_lora": (_I, [_P, _P, _I, _P]),
     "ttl_adamw_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
     "ttl_lora_reset": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "ttl_scaler_config": (_I, [_P, _I, _F, _F, _F, _I]),
+    "ttl_scaler_state": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ttl_scaler_unscale": (_I, [_P, _P, _Z, _P]),
+    "ttl_optimizer_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
     "ttl_episode": (_I, [_P, C.POINTER(ttl_episode_args), _P]),
     "ttl_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ttl_gemm_nt_epi": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P]),

@@ -151,6 +151,12 @@ class _TextModeEngine:
     def adamw_step(self, *a, **k):
         return self.txt.adamw_step(*a, **k)
 
+    def optimizer_step(self, *a, **k):
+        return self.txt.optimizer_step(*a, **k)
+
+    def scaler_state(self):
+        return self.txt.scaler_state()
+
     def lora_reset(self, *a, **k):
         return self.txt.lora_reset(*a, **k)
 

@@ -6,8 +6,9 @@ forward -> fused entropy / selection / weighted loss + analytic dlogits -> trunc
 backward -> fused AdamW on the flat LoRA buffer.  The optimizer / scaler objects the reference
 passes in stay consistent: hyper-parameters are read from ``optimizer.param_groups``, Adam state
 lives in ``optimizer.state`` (so ``optimizer.load_state_dict(optim_state)`` at ttl.py:344 resets it
-exactly like in the reference), ``scaler.update()`` remains callable (bf16 needs no loss scale,
-non-finite gradients are skipped inside the AdamW kernel — the GradScaler contract).
+exactly like in the reference); the GradScaler contract (scale the loss, unscale the gradients, skip the WHOLE step
+and halve the scale on inf/nan, double it after growth_interval clean steps, keep the scale across images) is kept by the
+context on the device (include/ttl_hip.h, ttl_optimizer_step) with the hyper-parameters of the scaler object passed in.
 """
 import math
 
@@ -60,6 +61,11 @@ def _adam_state(optimizer, model, params):
     return int(st[p0]["step"].item())
 
 
+def _scaled_engine(eng):
+    """The context whose backward carries the loss scale: the text tower's in text mode, else the engine itself."""
+    return getattr(eng, "txt", eng)
+
+
 def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin, margin, targets=None, flag=True,
                           group=None):
     """deyo.py:92-196 on the HIP path.  Returns (outputs, backward, final_backward)."""
@@ -68,6 +74,7 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     if getattr(args, "reweight_plpd", 0):
         raise NotImplementedError("reweight_plpd: the term is commented out in the reference (deyo.py:176)")
     eng = model._ensure_engine()
+    _scaled_engine(eng).bind_scaler(scaler)
     if not flag:
         return eng.forward(x, save=False)
     params, lr, betas, eps, wd = _adam_hparams(optimizer, model)
@@ -102,14 +109,14 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     eng.backward(L["dlogits"])                                                   # deyo.py:185-186
     for p, gslice in zip(params, _grad_views(eng, params)):
         p.grad = gslice
-    eng.adamw_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd,
-                   n_selected=L["n"])                                            # deyo.py:187
-    n = int(L["n"].item())                                                       # the only host sync of the step
-    if n:
+    # scaler.step(optimizer); scaler.update()  (deyo.py:187-188): the context's GradScaler state decides — the whole
+    # step or none of it on inf/nan gradients, dynamic loss scale in the fp16 build (the state lives on the device;
+    # the torch scaler object only supplies its hyper-parameters, see TTLEngine.bind_scaler)
+    eng.optimizer_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd, n_selected=L["n"])
+    n = int(L["n"].item())                                                       # the host sync of the step
+    if n and eng.scaler_state()["optimizer_steps"] == step + 1:                  # taken (not skipped on inf/nan)
         for p in params:
             optimizer.state[p]["step"] += 1
-    if scaler is not None and hasattr(scaler, "update") and getattr(scaler, "is_enabled", lambda: False)():
-        pass  # nothing was scaled: there is no inf/nan bookkeeping to feed scaler.update() with
     return outputs, (n if backward is None else backward), n
 
 

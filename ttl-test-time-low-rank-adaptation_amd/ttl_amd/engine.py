@@ -169,6 +169,39 @@ class TTLEngine:
             self._check(self.lib.ttl_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
                                                betas[1], eps, weight_decay, int(step), _ptr(n_selected), _stream()))
 
+    # ---- GradScaler contract (ttl.py:222, deyo.py:186-188): state on the device, see include/ttl_hip.h
+    def scaler_config(self, dynamic=True, init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self._check(self.lib.ttl_scaler_config(self._h, int(bool(dynamic)), float(init_scale), float(growth_factor),
+                                               float(backoff_factor), int(growth_interval)))
+
+    def bind_scaler(self, scaler):
+        """Adopt the hyper-parameters of the torch GradScaler the reference passes around (ttl.py:222).  Only the
+        fp16-operand build scales its backward; bf16 has fp32's exponent range and keeps scale 1.  Idempotent per object."""
+        if scaler is None or self.precision != "fp16" or getattr(self, "_scaler_id", None) == id(scaler):
+            return
+        if hasattr(scaler, "is_enabled") and not scaler.is_enabled():
+            return
+        self.scaler_config(True, float(scaler.get_scale()), float(scaler.get_growth_factor()), float(scaler.get_backoff_factor()),
+                           int(scaler.get_growth_interval()))
+        self._scaler_id = id(scaler)
+
+    def scaler_state(self):
+        """dict(scale, growth_tracker, skipped_steps, optimizer_steps); synchronises."""
+        sc, tr, sk, st = C.c_float(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.ttl_scaler_state(self._h, C.byref(sc), C.byref(tr), C.byref(sk), C.byref(st)))
+        return dict(scale=sc.value, growth_tracker=tr.value, skipped_steps=sk.value, optimizer_steps=st.value)
+
+    def scaler_unscale(self, grads):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_scaler_unscale(self._h, _ptr(grads), grads.numel(), _stream()))
+
+    def optimizer_step(self, params, grads, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, n_selected=None):
+        """scaler.step(optimizer) + scaler.update(): AdamW over the flat buffer — the whole step or none of it."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_optimizer_step(self._h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
+                                                    betas[1], eps, weight_decay, int(step),
+                                                    _ptr(n_selected) if n_selected is not None else None, _stream()))
+
     def lora_reset(self, params, snapshot, m=None, v=None):
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_lora_reset(_ptr(params), _ptr(snapshot), _ptr(m), _ptr(v), params.numel(), _stream()))

@@ -39,6 +39,7 @@ def test_time_tuning(model, inputs, optimizer, scaler, args):
     # TPT-style objective on the LoRA parameters (ttl.py:87-108): select once, then minimise the
     # entropy of the view-averaged prediction over the cached selection.
     eng = model._ensure_engine()
+    _deyo._scaled_engine(eng).bind_scaler(scaler)
     params, lr, betas, eps, wd = _adam_hparams(optimizer, model)
     if int(inputs.shape[0] * args.selection_p) == 0:
         raise ValueError("int(n_views * selection_p) == 0: the reference averages an empty selection here (nan)")
@@ -52,9 +53,10 @@ def test_time_tuning(model, inputs, optimizer, scaler, args):
         eng.backward(sel["dlogits"])
         for p, g in zip(params, _grad_views(eng, params)):
             p.grad = g
-        eng.adamw_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd)
-        for p in params:
-            optimizer.state[p]["step"] += 1
+        eng.optimizer_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd)   # ttl.py:106-108
+        if eng.scaler_state()["optimizer_steps"] == step + 1:       # taken (GradScaler skips the whole step on inf/nan)
+            for p in params:
+                optimizer.state[p]["step"] += 1
     return
 
 
