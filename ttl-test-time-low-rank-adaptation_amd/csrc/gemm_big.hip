@@ -56,6 +56,9 @@ constexpr int NTHR = 512;
 #ifndef TTL_BIG_PRIO
 #define TTL_BIG_PRIO 0
 #endif
+#ifndef TTL_BIG_EPI_OVERLAP
+#define TTL_BIG_EPI_OVERLAP 1
+#endif
 template <int S, int NS, int NV, int NM, bool MFIRST = false>
 struct Mix {
     static __device__ __forceinline__ void run() {
@@ -80,10 +83,11 @@ __device__ __forceinline__ void wait_dma() {
 // Epilogue of this kernel: bias and residual were folded into the accumulators' initial value, so the only memory
 // operations here are stores (an ordinary load next to the next tile's in-flight LDS-DMA makes hipcc wait vmcnt(0),
 // which drains that prefetch).  Register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column 4*li + nt.
+constexpr int EPI_GELU_C2 = 100;   // internal: EPI_GELU with the second (pre-activation) output, kept branch-free
+
 template <int EPI, int MT>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+__device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 (&acc)[MT][4], int mt, int rbase, int n0, int lg) {
+    {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t m = (size_t)(rbase + mt * 16 + 4 * lg + r);
@@ -91,8 +95,8 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&ac
             if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
                 st_out((f32x4*)((float*)a.C + m * a.ldc + n0), f32x4{v0, v1, v2, v3});
             } else {
-                if constexpr (EPI == EPI_GELU) {
-                    if (a.C2) __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)(a.C2 + m * a.ldc2 + n0));
+                if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_C2) {
+                    if constexpr (EPI == EPI_GELU_C2) __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)(a.C2 + m * a.ldc2 + n0));
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                     __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)((op_t*)a.C + m * a.ldc + n0));
                 } else {
@@ -101,6 +105,12 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&ac
             }
         }
     }
+}
+
+template <int EPI, int MT>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) big_epilogue_row<EPI, MT>(a, acc, mt, rbase, n0, lg);
 }
 
 struct TileMap {
@@ -337,22 +347,36 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             issue_odd(0, cur); issue_uni(0, cur);
             if constexpr (STAGES == 3) { issue_odd(1, nn); issue_uni(1, nn); }
         }
-        // ---- step nk-1
+        // ---- step nk-1, row-major: the last K-tile's eight MFMAs of output row block mt, then that row block's epilogue
+        // (pack / activation / stores) while the next row block multiplies (TTL_BIG_EPI_OVERLAP: 0 = all MFMAs, then the
+        // whole epilogue with the matrix pipe idle)
         {
             load_frags(nxt, 0, xf0, wf0);
             mma(xf1, wf1);
             Mix<0, MT + 4, 0, 4 * MT>::run();
             __builtin_amdgcn_sched_barrier(0);
             load_frags(nxt, 1, xf1, wf1);
-            mma(xf0, wf0);
-            mma(xf1, wf1);
+            if constexpr (TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf0[mt], wf0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf1[mt], wf1[nt], acc[mt][nt], 0, 0, 0);
+                    if (mt > 0) big_epilogue_row<EPI, MT>(a, acc, mt - 1, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+                }
+                big_epilogue_row<EPI, MT>(a, acc, MT - 1, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+            } else {
+                mma(xf0, wf0);
+                mma(xf1, wf1);
+            }
         }
         if (TTL_GEMM_DIAG == 5) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
-        } else big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+        } else if (!(TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0)) big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
         if (!more) break;
         slot = nslot;
         first = false;
@@ -444,7 +468,7 @@ hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
         case EPI_F32: return launch_big_v<EPI_F32>(a, mt, stages, order, max_blocks, s);
         case EPI_OP: return launch_big_v<EPI_OP>(a, mt, stages, order, max_blocks, s);
         case EPI_RESID_F32: return launch_big_v<EPI_RESID_F32>(a, mt, stages, order, max_blocks, s);
-        case EPI_GELU: return launch_big_v<EPI_GELU>(a, mt, stages, order, max_blocks, s);
+        case EPI_GELU: return a.C2 ? launch_big_v<EPI_GELU_C2>(a, mt, stages, order, max_blocks, s) : launch_big_v<EPI_GELU>(a, mt, stages, order, max_blocks, s);
         default: break;
     }
     return hipErrorInvalidValue;

@@ -45,6 +45,7 @@ __device__ __forceinline__ float matvec64(const float* __restrict__ in_lds, cons
     if (o < O) {
         const float* w = W + o;
         int i = slice;
+        // (8-fold unrolling for 32 loads in flight per thread was tried: the class got 2x SLOWER in situ)
 #pragma unroll 2
         for (; i + 12 < I; i += 16) {
             a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
