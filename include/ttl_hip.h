@@ -54,8 +54,12 @@ typedef struct ttl_config {
                          * context_length tokens, pooled at the end-of-text token; image_size / patch_size unused */
     int context_length; /* text tower: 77 */
     int vocab_size;     /* text tower: 49408 */
+    int lora_targets;   /* attention projections that carry an adapter (peft LoraConfig.target_modules, clip/custom_clip.py:586):
+                         * bit mask of TTL_LORA_*; 0 = the reference's q_proj + v_proj.  The bound LoRA buffer holds, per trained
+                         * layer, A [r,D] then B [D,r] of every enabled projection in the order q, k, v, out. */
 } ttl_config;
 enum { TTL_TOWER_IMAGE = 0, TTL_TOWER_TEXT = 1 };
+enum { TTL_LORA_Q = 1, TTL_LORA_K = 2, TTL_LORA_V = 4, TTL_LORA_O = 8 };
 
 typedef struct ttl_ctx ttl_ctx;
 

@@ -231,6 +231,11 @@ class VitOracle:
     def trained(self, i):
         return self.cfg.layer_lo <= i <= self.cfg.layer_hi
 
+    def targets(self, i):
+        """Projections of layer i that carry an adapter (peft LoraConfig.target_modules, clip/custom_clip.py:586: q_proj and
+        v_proj in the reference; k_proj / out_proj when configured)."""
+        return tuple(getattr(self.cfg, "lora_targets", ("q_proj", "v_proj"))) if self.trained(i) else ()
+
     # -- forward
     def embed(self, x):
         """modeling_clip.py:202-218: conv patch-embed (no bias) + cls + pos."""
@@ -254,7 +259,7 @@ class VitOracle:
         U = {}
         for pj in ("q_proj", "k_proj", "v_proj"):
             y = x1 @ r(self._lw(i, f"self_attn.{pj}.weight")).T + self._lw(i, f"self_attn.{pj}.bias")
-            if pj != "k_proj" and self.trained(i):
+            if pj in self.targets(i):
                 # peft LoRA Linear (dropout inactive in eval, ttl.py:312)
                 A, B = self._lora(i, pj, "A"), self._lora(i, pj, "B")
                 U[pj] = r(s * (x1 @ r(A).T))          # HIP path stores s·U in bf16
@@ -273,6 +278,9 @@ class VitOracle:
         o = r(Pm) @ v
         o = r(o.transpose(0, 2, 1, 3).reshape(N, T, D).astype(np.float32))
         a = o @ r(self._lw(i, "self_attn.out_proj.weight")).T + self._lw(i, "self_attn.out_proj.bias")
+        if "out_proj" in self.targets(i):
+            U["out_proj"] = r(s * (o @ r(self._lora(i, "out_proj", "A")).T))
+            a = a + U["out_proj"] @ r(self._lora(i, "out_proj", "B")).T
         hm = (h + a).astype(np.float32)
         x2, mu2, rs2 = layer_norm(hm, self._lw(i, "layer_norm2.weight"), self._lw(i, "layer_norm2.bias"), c.ln_eps)
         x2 = r(x2)
@@ -353,7 +361,17 @@ class VitOracle:
             dx2 = du @ r(self._lw(i, "mlp.fc1.weight"))
             dhm = dh + layer_norm_bwd(dx2, sv["h_mid"], sv["mu2"], sv["rs2"], self._lw(i, "layer_norm2.weight"))
             # attention
-            do = r(r(dhm) @ r(self._lw(i, "self_attn.out_proj.weight")))
+            base = f"{self.tower}.encoder.layers.{i}.self_attn."
+            tg = self.targets(i)
+            do = r(dhm) @ r(self._lw(i, "self_attn.out_proj.weight"))
+            if "out_proj" in tg:
+                Ao, Bo = self._lora(i, "out_proj", "A"), self._lora(i, "out_proj", "B")
+                dhm16 = r(dhm).reshape(N * T, D)
+                dUo = r(s * (dhm16 @ r(Bo)))
+                do = do + (dUo @ r(Ao)).reshape(N, T, D)
+                grads[base + "out_proj.lora_B.default.weight"] = (dhm16.T @ sv["U"]["out_proj"].reshape(N * T, -1)).astype(np.float32)
+                grads[base + "out_proj.lora_A.default.weight"] = (dUo.T @ sv["o"].reshape(N * T, D)).astype(np.float32)
+            do = r(do.astype(np.float32))
             dO = do.reshape(N, T, Hh, dhd).transpose(0, 2, 1, 3)
             q, k, v = sv["q"], sv["k"], sv["v"]
             sc = (q @ k.transpose(0, 1, 3, 2)) * np.float32(dhd ** -0.5)
@@ -369,10 +387,13 @@ class VitOracle:
             merge = lambda a: r(a.transpose(0, 2, 1, 3).reshape(N * T, D).astype(np.float32))
             dq, dv = merge(dQ), merge(dV)
             x1 = sv["x1"].reshape(N * T, D)
-            base = f"{self.tower}.encoder.layers.{i}.self_attn."
+            dk = None
+            if "k_proj" in tg or not first:        # (the first trained layer needs dK only for a k_proj adapter)
+                dK = (dS.transpose(0, 1, 3, 2) @ q) * np.float32(dhd ** -0.5)
+                dk = merge(dK)
             dU = {}
-            for pj, dproj in (("q_proj", dq), ("v_proj", dv)):
-                if not self.trained(i):
+            for pj, dproj in (("q_proj", dq), ("k_proj", dk), ("v_proj", dv)):
+                if pj not in tg:
                     continue
                 A, B = self._lora(i, pj, "A"), self._lora(i, pj, "B")
                 Us = sv["U"][pj].reshape(N * T, -1)            # = s·x1·A^T
@@ -381,13 +402,11 @@ class VitOracle:
                 grads[base + pj + ".lora_A.default.weight"] = (dU[pj].T @ x1).astype(np.float32)
             if first:
                 break
-            dK = (dS.transpose(0, 1, 3, 2) @ q) * np.float32(dhd ** -0.5)
-            dk = merge(dK)
             dx1 = (dq @ r(self._lw(i, "self_attn.q_proj.weight"))
                    + dk @ r(self._lw(i, "self_attn.k_proj.weight"))
                    + dv @ r(self._lw(i, "self_attn.v_proj.weight")))
-            if self.trained(i):
-                dx1 = dx1 + dU["q_proj"] @ r(self._lora(i, "q_proj", "A")) + dU["v_proj"] @ r(self._lora(i, "v_proj", "A"))
+            for pj in dU:
+                dx1 = dx1 + dU[pj] @ r(self._lora(i, pj, "A"))
             dx1 = dx1.reshape(N, T, D)
             dh = dhm + layer_norm_bwd(dx1, sv["h_in"], sv["mu1"], sv["rs1"], self._lw(i, "layer_norm1.weight"))
         return grads
@@ -445,10 +464,12 @@ class TextOracle(VitOracle):
 
 # ---------------------------------------------------------------------------- episode
 def trainable_names(cfg, tower="vision_model"):
-    """Order of the 12 param groups at ttl.py:195-213: per layer q.A, q.B, v.A, v.B."""
+    """Order of the 12 param groups at ttl.py:195-213: per layer q.A, q.B, v.A, v.B (with k_proj / out_proj adapters
+    configured: q, k, v, out)."""
     out = []
+    tg = getattr(cfg, "lora_targets", ("q_proj", "v_proj"))
     for i in range(cfg.layer_lo, cfg.layer_hi + 1):
-        for pj in ("q_proj", "v_proj"):
+        for pj in [t for t in ("q_proj", "k_proj", "v_proj", "out_proj") if t in tg]:
             for ab in ("A", "B"):
                 out.append(f"{tower}.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight")
     return out

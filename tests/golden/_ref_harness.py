@@ -74,7 +74,9 @@ def install_import_stubs():
         def __init__(self, r=8, lora_alpha=8, target_modules=None, lora_dropout=0.0,
                      bias="none", task_type=None, **kw):
             self.r, self.lora_alpha = r, lora_alpha
-            self.target_modules, self.lora_dropout = list(target_modules), lora_dropout
+            # TARGET_MODULES_OVERRIDE: harness-side override of the list the reference hard-codes (clip/custom_clip.py:586),
+            # used ONLY by the k_proj / out_proj fixtures of make_golden.py (the reference itself is not edited)
+            self.target_modules, self.lora_dropout = list(TARGET_MODULES_OVERRIDE or target_modules), lora_dropout
 
     class LoraLinear(nn.Module):
         def __init__(self, base: nn.Linear, r, alpha, dropout):
@@ -119,6 +121,9 @@ def install_import_stubs():
     _mod("peft", LoraConfig=LoraConfig, get_peft_model=get_peft_model,
          prepare_model_for_int8_training=prepare_model_for_int8_training,
          TaskType=types.SimpleNamespace())
+
+
+TARGET_MODULES_OVERRIDE = None
 
 
 def make_clip_model(cfg, seed, text_seed=1234, text_cfg=None):

@@ -49,6 +49,12 @@ CASES = {
     # BASELINE.json configs[2]'s single-GPU workload: the 1000 ImageNet labels
     "b16_n64_k1000_ent0": ("ViT-B/16", 64, 1000, {}),
     "b16_n64_k1000_ent1": ("ViT-B/16", 64, 1000, {"filter_ent": 1}),
+    # adapters on all four attention projections (BASELINE.json north_star).  The reference hard-codes q_proj + v_proj in its
+    # LoraConfig (clip/custom_clip.py:586): these two cases run the UNMODIFIED reference with the harness's peft stand-in told to
+    # wrap k_proj / out_proj too (_ref_harness.TARGET_MODULES_OVERRIDE); the reference's LoRA_AB still (re-)initialises q and v
+    # only, so k / out keep the stand-in's kaiming A and zero B.
+    "tiny_qkvo_deyo": ("tiny", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"]}),
+    "tiny_qkvo_steps2": ("tiny", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "tta_steps": 2}),
 }
 
 
@@ -71,6 +77,11 @@ def build_reference(case):
     cfg = get_config(arch)
     rank = over.get("rank", 16)
     cfg = cfg.replace(rank=rank)
+    over = dict(over)
+    targets = over.pop("target_modules", None)
+    H.TARGET_MODULES_OVERRIDE = targets
+    if targets:
+        cfg = cfg.replace(lora_targets=tuple(targets))
     args = default_args(**over)
     args.layer_range = [cfg.layer_lo, cfg.layer_hi]
     args.batch_size = n_views
@@ -94,10 +105,10 @@ def build_reference(case):
     groups = []
     for i, layer in enumerate(model.image_encoder.vision_model.encoder.layers):
         if args.layer_range[0] <= i <= args.layer_range[1]:
-            groups += [{"params": layer.self_attn.q_proj.lora_A.parameters()},
-                       {"params": layer.self_attn.q_proj.lora_B.parameters()},
-                       {"params": layer.self_attn.v_proj.lora_A.parameters()},
-                       {"params": layer.self_attn.v_proj.lora_B.parameters()}]
+            for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):      # ttl.py:195-213 lists q and v; k / out when wrapped
+                m = getattr(layer.self_attn, pj)
+                if hasattr(m, "lora_A"):
+                    groups += [{"params": m.lora_A.parameters()}, {"params": m.lora_B.parameters()}]
     opt = torch.optim.AdamW(groups, lr=args.lr)
     opt_state = copy.deepcopy(opt.state_dict())
     scaler = torch.cuda.amp.GradScaler(init_scale=1000)   # disabled on CPU (Q14)
@@ -184,7 +195,7 @@ def run_case(case):
         extra = {}
     trained = [k for k in lora0 if any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1))]
     out = dict(
-        arch=cfg.name, rank=cfg.rank, n_views=N, n_classes=K, weight_seed=0, view_seed=7,
+        arch=cfg.name, rank=cfg.rank, lora_targets=np.array(list(cfg.lora_targets)), n_views=N, n_classes=K, weight_seed=0, view_seed=7,
         weights_sha256=synth.checksum(synth.vision_weights(cfg, 0)),
         x_sha256=synth.checksum([x.numpy()]),
         objective="deyo" if args.deyo_selection else "tpt",

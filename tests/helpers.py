@@ -13,6 +13,8 @@ def load_case(name):
     """-> (golden npz, cfg, W, x, lora0, tfeat) rebuilt from seeds and checked by sha256."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = get_config(str(g["arch"])).replace(rank=int(g["rank"]))
+    if "lora_targets" in g.files:          # fixtures with adapters beyond the reference's q_proj / v_proj
+        cfg = cfg.replace(lora_targets=tuple(str(t) for t in g["lora_targets"]))
     W = synth.vision_weights(cfg, int(g["weight_seed"]))
     assert synth.checksum(W) == str(g["weights_sha256"]), "synthetic weights drifted from the fixture"
     x = synth.views(cfg, int(g["n_views"]), int(g["view_seed"]))

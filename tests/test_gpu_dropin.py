@@ -321,3 +321,49 @@ def test_eval_routes_filter_plpd_to_the_stepwise_loop():
         hits += torch.stack([h1, h5])
     top1, top5 = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=2)
     assert abs(top1 - 100.0 * hits[0].item() / 4) < 1e-9 and abs(top5 - 100.0 * hits[1].item() / 4) < 1e-9
+
+
+def test_target_modules_k_and_out_on_the_host_surface():
+    """ClipTestTimeTuning(target_modules=[q, k, v, out]): parameter tree, LoRA_AB snapshot / reset, the reference-shaped loop,
+    and the result against the reference-generated fixture tiny_qkvo_deyo."""
+    from ttl_amd.custom_clip import ClipTestTimeTuning
+    from ttl_amd.ttl import test_time_tuning
+    g, cfg, W, x, lora0, tf = load_case("tiny_qkvo_deyo")
+    tg = list(cfg.lora_targets)
+    model = ClipTestTimeTuning(0, [f"c{i}" for i in range(tf.shape[0])], None, arch=cfg.name, layer_range=[cfg.layer_lo, cfg.layer_hi],
+                               init_method="xavier", lora_encoder="image", rank=cfg.rank, max_views=x.shape[0], max_classes=tf.shape[0],
+                               weight_seed=0, target_modules=tg)
+    names = [n for n, _ in model.named_parameters() if "lora_" in n]
+    assert sum("k_proj" in n for n in names) == 2 * cfg.layers and sum("out_proj" in n for n in names) == 2 * cfg.layers
+    with torch.no_grad():
+        for i, layer in enumerate(model.image_encoder.vision_model.encoder.layers):
+            snap = []
+            for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                for ab in ("A", "B"):
+                    w = getattr(getattr(layer.self_attn, pj), f"lora_{ab}").default.weight
+                    w.copy_(torch.from_numpy(lora0[f"vision_model.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight"]))
+                    snap.append(w.detach().clone())
+            model.LoRA_AB.init_weights[i] = tuple(snap)
+    tft = torch.from_numpy(tf).cuda()
+    model.get_text_features = lambda: tft
+    model._text_dirty = True
+    params = model.trainable_lora_parameters()
+    assert len(params) == (cfg.layer_hi - cfg.layer_lo + 1) * 8
+    for n, p in model.named_parameters():
+        p.requires_grad_(any(p is q for q in params))
+    opt = torch.optim.AdamW([{"params": [p]} for p in params], lr=5e-3)
+    opt_state = copy.deepcopy(opt.state_dict())
+    xd = torch.from_numpy(x).cuda()
+    outs = []
+    for rep in range(2):
+        with torch.no_grad():
+            model.LoRA_reset()
+        opt.load_state_dict(opt_state)
+        test_time_tuning(model, xd, opt, None, ref_args())
+        with torch.no_grad():
+            outs.append(model(xd[:1]).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])                       # k / out adapters are reset too
+    assert max_rel(outs[0], g["logits1"]) < 3e-2 and int(outs[0].argmax()) == int(g["top5"][0, 0])
+    got = {n.replace("image_encoder.", ""): p.detach().cpu().numpy() for n, p in model.named_parameters() if "lora_" in n}
+    frac_bad = np.mean([float((np.abs(got[k[6:]] - g[k]) > 1e-3).mean()) for k in g.files if k.startswith("lora1/")])
+    assert frac_bad < 0.2, frac_bad

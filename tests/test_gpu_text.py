@@ -295,3 +295,44 @@ def test_plpd_filter_text_mode_matches_reference():
         out = model(x[:1])
     assert max_rel(out.cpu().numpy(), g["logits1"]) < 3e-2
     assert int(out.argmax()) == int(g["top5"][0, 0])
+
+
+def test_text_tower_k_and_out_proj_adapters_vs_oracle():
+    """--lora_encoder text with adapters on q, k, v and out_proj: the end-of-text pooling makes the top layer's out_proj
+    gradients run on gathered rows (one per prompt, positions differ)."""
+    import numpy as np
+    from oracle import ttl_oracle as O
+    from helpers import max_rel
+    from ttl_amd import synth
+    from ttl_amd.config import get_config, get_text_config
+    from ttl_amd.custom_clip import build_text_mode_engine
+    tg = ("q_proj", "k_proj", "v_proj", "out_proj")
+    vcfg, tcfg = get_config("tiny"), get_text_config("tiny").replace(lora_targets=tg)
+    Wv, Wt = synth.vision_weights(vcfg, 0), synth.text_weights(tcfg, 0)
+    lora0 = synth.lora_init(tcfg, 0, tower="text_model")
+    rng = np.random.default_rng(5)
+    for k in lora0:
+        if "lora_B" in k:
+            lora0[k] = (rng.standard_normal(lora0[k].shape) * 0.02).astype(np.float32)
+    K, N = 6, 4
+    ids = synth.token_ids(K, tcfg, 3)
+    x = synth.views(vcfg, N, 5)
+    eng = build_text_mode_engine(vcfg, tcfg, Wv, Wt, torch.from_numpy(ids), float(np.exp(Wv["logit_scale"])), "cuda:0", N, K, "bf16")
+    names = O.trainable_names(tcfg, "text_model")
+    flat = torch.cat([torch.from_numpy(lora0[k]).reshape(-1) for k in names]).cuda().contiguous()
+    eng.bind_lora(flat)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    l1 = eng.episode(torch.from_numpy(x).cuda(), snap, m, v, n_updates=1)
+    torch.cuda.synchronize()
+    trace = []
+    ob = O.episode_text(vcfg, tcfg, Wv, Wt, lora0, x, ids, prec="bf16", trace=trace)
+    g = eng.grads.cpu().numpy()
+    off = 0
+    gmax = max(float(np.abs(trace[-1]["grads"][k]).max()) for k in names)
+    for k in names:
+        gr = trace[-1]["grads"][k]
+        got = g[off:off + gr.size].reshape(gr.shape)
+        off += gr.size
+        assert max_rel(got, gr) < 4e-2 or np.abs(got - gr).max() < 3e-3 * gmax, (k, max_rel(got, gr))
+    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 2e-2
+    eng.close()

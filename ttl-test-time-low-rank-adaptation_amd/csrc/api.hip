@@ -56,8 +56,11 @@ struct Layer {
     op_t* woT;    // [D][D]   (= Wo^T: [in][out] -> rows = in)
     op_t* w1T;    // [D][F]
     op_t* w2T;    // [F][D]
-    op_t* acat;   // [2r][D]
-    op_t* btcat;  // [2r][D]
+    op_t* acat;   // [nqkv*r][D]  rows of A of the enabled q/k/v adapters
+    op_t* btcat;  // [nqkv*r][D]  rows of B^T
+    op_t *acat_o, *btcat_o;   // [r][D] out_proj adapter: A_o, B_o^T
+    int ldwo;     // row pitch of wo / woT: D, or D+64 when the layer carries an out_proj adapter (K-extension columns)
+    int ldat;     // row pitch of the layer's saved attention output (same rule)
     // saved activations (trained layers only)
     float* h_in; float* h_mid;
     op_t* x1ext; op_t* qkv; op_t* attn; op_t* u;
@@ -73,6 +76,9 @@ struct Layer {
 struct ttl_ctx {
     ttl_config c;
     int D, F, H, T, E, L, P, S, G2, r, Kp, ldx, ldw, ldwt, nT, nS;  // nT: layers with adapters, nS: saved layers (layer_lo..L-1)
+    // adapters per layer: tg = mask of TTL_LORA_*, ntg of them, nqkv among q/k/v at slots sq/sk/sv (-1 = none), has_o;
+    // ext = K-extension columns of the QKV GEMMs (nqkv*r rounded up to 64), ldh = pitch of the bf16 stream-gradient buffers
+    int tg, ntg, nqkv, sq, sk, sv, has_o, ext, ldh;
     int Mmax;
     float scaling;
     std::vector<void*> allocs;
@@ -104,6 +110,7 @@ struct ttl_ctx {
     float *dh, *dh2, *dx; op_t *dh16, *dbig, *dattn, *dqkv;
     // top-layer backward works on the CLS rows only (compact [N, .] buffers)
     float *dcls, *dxc, *dhmc; op_t *dcls16, *dgc, *dhmc16, *doc;
+    op_t* att_g;   // text tower, out_proj adapter in the top layer: the pooled rows of the saved attention output, compact [N][D+64]
     float* wg_partial;
     float* gemm_ws; size_t gemm_ws_bytes;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
@@ -156,6 +163,7 @@ int check_config(const ttl_config* k) {
     int T = k->tower == TTL_TOWER_TEXT ? k->context_length : (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
     if (T > 288) return fail(TTL_EINVAL, "token count %d > 288 unsupported", T);
     if (k->max_views < 1 || k->max_classes < 1 || k->embed < 1 || k->embed > 4096) return fail(TTL_EINVAL, "bad capacities");
+    if (k->lora_targets < 0 || k->lora_targets > 15) return fail(TTL_EINVAL, "lora_targets must be a mask of TTL_LORA_Q|K|V|O (got %d)", k->lora_targets);
     return 0;
 }
 
@@ -166,9 +174,18 @@ void set_geometry(ttl_ctx* c, const ttl_config* k) {
     c->S = k->image_size; c->r = k->rank;
     if (c->text) { c->G2 = 0; c->T = k->context_length; c->Kp = 64; }
     else { c->G2 = (c->S / c->P) * (c->S / c->P); c->T = c->G2 + 1; c->Kp = round_up(3 * c->P * c->P, 64); }
-    c->ldx = c->D + 64;        // x1ext: D | 2r LoRA cols | zero pad
-    c->ldw = c->D + 64;        // wqkv rows
-    c->ldwt = 3 * c->D + 64;   // wqkvT rows / dqkv rows
+    c->tg = k->lora_targets ? k->lora_targets : (TTL_LORA_Q | TTL_LORA_V);   // the reference's target_modules (custom_clip.py:586)
+    c->sq = c->sk = c->sv = -1; c->nqkv = 0;
+    if (c->tg & TTL_LORA_Q) c->sq = c->nqkv++;
+    if (c->tg & TTL_LORA_K) c->sk = c->nqkv++;
+    if (c->tg & TTL_LORA_V) c->sv = c->nqkv++;
+    c->has_o = (c->tg & TTL_LORA_O) != 0;
+    c->ntg = c->nqkv + c->has_o;
+    c->ext = round_up(c->nqkv * c->r > 0 ? c->nqkv * c->r : 1, 64);
+    c->ldx = c->D + c->ext;        // x1ext: D | nqkv*r LoRA cols | zero pad
+    c->ldw = c->D + c->ext;        // wqkv rows
+    c->ldwt = 3 * c->D + c->ext;   // wqkvT rows / dqkv rows
+    c->ldh = c->D + (c->has_o ? 64 : 0);   // dh16 / dhmc16: D | r cols of dU_o | zero pad
     c->nT = k->layer_hi - k->layer_lo + 1;
     c->nS = k->layers - k->layer_lo;
     c->Mmax = round_up(k->max_views * c->T, 1280);  // padded: the big GEMM tiles store whole row tiles unguarded
@@ -227,11 +244,12 @@ size_t ttl_workspace_bytes(const ttl_config* k) {
     if (check_config(k)) return 0;
     ttl_ctx t; set_geometry(&t, k);
     size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nS, N = k->max_views;   // (saved layers: layer_lo..L-1)
-    size_t w = L * (3 * D * t.ldw + D * D + 2 * D * F) * 2 + nT * (D * t.ldwt + D * D + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
+    const size_t ldo = D + (t.has_o ? 64 : 0);
+    size_t w = L * (3 * D * t.ldw + D * ldo + 2 * D * F) * 2 + nT * (D * t.ldwt + D * ldo + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
                (t.text ? (size_t)k->vocab_size * D * 4 : 0);
-    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * D + M * F) * 2 +
-                 (M * D + M * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * D + M * F + M * D + M * t.ldwt) * 2 +
-                 (size_t)lora_wgrad_chunks((int)M) * 4 * t.r * D * 4;
+    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * ldo + M * F) * 2 +
+                 (M * D + M * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * 2 +
+                 (size_t)lora_wgrad_chunks((int)M) * 2 * t.ntg * t.r * D * 4;
     return w + act;
 }
 
@@ -253,16 +271,17 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
         memset(&l, 0, sizeof l);
         l.trained = (i >= k->layer_lo);
         l.lora = (i >= k->layer_lo && i <= k->layer_hi);
+        l.ldwo = l.ldat = (int)D + ((l.lora && c->has_o) ? 64 : 0);
         ALLOC(l.wqkv, 3 * D * c->ldw, true); ALLOC(l.bqkv, 3 * D, true);
-        ALLOC(l.wo, D * D, false); ALLOC(l.bo, D, true);
+        ALLOC(l.wo, D * l.ldwo, true); ALLOC(l.bo, D, true);
         ALLOC(l.w1, F * D, false); ALLOC(l.b1, F, true);
         ALLOC(l.w2, D * F, false); ALLOC(l.b2, D, true);
         ALLOC(l.ln1g, D, true); ALLOC(l.ln1b, D, true); ALLOC(l.ln2g, D, true); ALLOC(l.ln2b, D, true);
         if (l.trained) {
-            ALLOC(l.wqkvT, D * c->ldwt, true); ALLOC(l.woT, D * D, false); ALLOC(l.w1T, D * F, false); ALLOC(l.w2T, F * D, false);
-            ALLOC(l.acat, 2 * r * D, true); ALLOC(l.btcat, 2 * r * D, true);
+            ALLOC(l.wqkvT, D * c->ldwt, true); ALLOC(l.woT, D * l.ldwo, true); ALLOC(l.w1T, D * F, false); ALLOC(l.w2T, F * D, false);
+            ALLOC(l.acat, 3 * r * D, true); ALLOC(l.btcat, 3 * r * D, true); ALLOC(l.acat_o, r * D, true); ALLOC(l.btcat_o, r * D, true);
             ALLOC(l.h_mid, M * D, false);  // h_in is a pointer into the stream buffers
-            ALLOC(l.x1ext, M * c->ldx, true); ALLOC(l.qkv, M * 3 * D, false); ALLOC(l.attn, M * D, false); ALLOC(l.u, M * F, false);
+            ALLOC(l.x1ext, M * c->ldx, true); ALLOC(l.qkv, M * 3 * D, false); ALLOC(l.attn, M * l.ldat, true); ALLOC(l.u, M * F, false);
             ALLOC(l.lse, N * H * T, false);
             ALLOC(l.mu1, M, false); ALLOC(l.rs1, M, false); ALLOC(l.mu2, M, false); ALLOC(l.rs2, M, false);
         }
@@ -290,11 +309,12 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     ALLOC(c->logits, N * k->max_classes, false); ALLOC(c->dlogits, N * k->max_classes, false);
     ALLOC(c->head_te, N * E, false); ALLOC(c->head_td, N * D, false);
     ALLOC(c->dh, M * D, false); ALLOC(c->dh2, M * D, false); ALLOC(c->dx, M * D, false);
-    ALLOC(c->dh16, M * D, false); ALLOC(c->dbig, M * F, false); ALLOC(c->dattn, M * D, false);
+    ALLOC(c->dh16, M * c->ldh, true); ALLOC(c->dbig, M * F, false); ALLOC(c->dattn, M * (D + 64), false);   // (dattn shares the saved attention output's pitch)
     ALLOC(c->dqkv, M * c->ldwt, true);
     ALLOC(c->dcls, N * D, false); ALLOC(c->dxc, N * D, false); ALLOC(c->dhmc, N * D, false);
-    ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * D, false); ALLOC(c->doc, N * D, false);
-    ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 4 * r * D, false);
+    ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * c->ldh, true); ALLOC(c->doc, N * D, false);
+    ALLOC(c->att_g, N * (D + 64), true);
+    ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 2 * c->ntg * r * D, false);
     c->gemm_ws_bytes = (size_t)8 << 20;
     ALLOC(c->gemm_ws, c->gemm_ws_bytes / sizeof(float), false);
     // (the text tower runs the loss on [views, prompts] logits: either count can be the larger one)
@@ -362,11 +382,11 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
             l.loaded |= bit;
             return 0;
         };
-        auto plain_w = [&](op_t* dst, op_t* dstT, size_t rows, size_t cols, unsigned bit) -> int {
+        auto plain_w = [&](op_t* dst, op_t* dstT, size_t rows, size_t cols, unsigned bit, int ld = 0, int ldT = 0) -> int {
             NEED(rows * cols);
             if ((rc = upload(c, data, count, &tmp))) return rc;
-            hipError_t e = launch_cast_f32_op(tmp, dst, count, s);
-            if (e == hipSuccess && dstT) e = launch_transpose_f32_op(tmp, (int)rows, (int)cols, dstT, (int)rows, s);
+            hipError_t e = ld ? launch_cast_rows_f32_op(tmp, (int)rows, (int)cols, dst, ld, s) : launch_cast_f32_op(tmp, dst, count, s);
+            if (e == hipSuccess && dstT) e = launch_transpose_f32_op(tmp, (int)rows, (int)cols, dstT, ldT ? ldT : (int)rows, s);
             if (e == hipSuccess) e = hipDeviceSynchronize();
             (void)hipFree(tmp);
             if (e != hipSuccess) return fail((int)e, "%s: %s", name, hipGetErrorString(e));
@@ -379,7 +399,7 @@ int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t coun
         if (t == "self_attn.q_proj.bias") { NEED(D); F32COPY(l.bqkv); l.loaded |= W_QB; return 0; }
         if (t == "self_attn.k_proj.bias") { NEED(D); F32COPY(l.bqkv + D); l.loaded |= W_KB; return 0; }
         if (t == "self_attn.v_proj.bias") { NEED(D); F32COPY(l.bqkv + 2 * D); l.loaded |= W_VB; return 0; }
-        if (t == "self_attn.out_proj.weight") return plain_w(l.wo, l.trained ? l.woT : nullptr, D, D, W_OW);
+        if (t == "self_attn.out_proj.weight") return plain_w(l.wo, l.trained ? l.woT : nullptr, D, D, W_OW, l.ldwo, l.ldwo);
         if (t == "self_attn.out_proj.bias") { NEED(D); F32COPY(l.bo); l.loaded |= W_OB; return 0; }
         if (t == "mlp.fc1.weight") return plain_w(l.w1, l.trained ? l.w1T : nullptr, F, D, W_1W);
         if (t == "mlp.fc1.bias") { NEED(F); F32COPY(l.b1); l.loaded |= W_1B; return 0; }
@@ -498,7 +518,7 @@ int ttl_set_prompts(ttl_ctx* c, const int* ids, int n_prompts, void* stream) {
 
 int ttl_bind_lora(ttl_ctx* c, float* params, float* grads, size_t n) {
     if (!c || !params || !grads) return fail(TTL_EINVAL, "null argument");
-    size_t want = (size_t)c->nT * 4 * c->r * c->D;
+    size_t want = (size_t)c->nT * c->ntg * 2 * c->r * c->D;
     if (n != want) return fail(TTL_EINVAL, "lora buffer has %zu elements, geometry needs %zu", n, want);
     c->lora_p = params; c->lora_g = grads; c->lora_n = n;
     return 0;
@@ -522,9 +542,13 @@ static int lora_refresh(ttl_ctx* c, hipStream_t s) {
     const size_t per = (size_t)c->r * c->D;
     for (int i = 0; i < c->nT; ++i) {
         Layer& l = c->layers[c->c.layer_lo + i];
-        const float* base = c->lora_p + (size_t)i * 4 * per;
-        HIP_TRY(launch_lora_refresh(base, base + per, base + 2 * per, base + 3 * per, c->D, c->r, l.wqkv, c->ldw, l.wqkvT, c->ldwt,
-                                    l.acat, l.btcat, s));
+        const float* base = c->lora_p + (size_t)i * c->ntg * 2 * per;
+        LoraPtrs P = {};
+        int k = 0;
+        for (int t = 0; t < 4; ++t)
+            if (c->tg & (1 << t)) { P.A[t] = base + (size_t)k * 2 * per; P.B[t] = P.A[t] + per; ++k; }
+        HIP_TRY(launch_lora_refresh(P, c->D, c->r, l.wqkv, c->ldw, l.wqkvT, c->ldwt, l.acat, l.btcat, l.wo, l.woT, l.ldwo, l.acat_o,
+                                    l.btcat_o, s));
     }
     return 0;
 }
@@ -585,14 +609,17 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         const int ldx1 = tr ? c->ldx : D;
         op_t* qkv = tr ? l.qkv : c->qkv;
         op_t* att = tr ? l.attn : c->attn;
+        const int ldat = tr ? l.ldat : D;              // (row pitch of att: K-extension columns for an out_proj adapter)
+        const bool lo_qkv = lo && c->nqkv > 0, lo_o = lo && c->has_o;
         float* h_in = h;  // trained layers write h_mid / h_out to fresh buffers, so h_in survives for LN1 backward
         {
             Prof p(c, 3, s);
             HIP_TRY(launch_layernorm(h_in, D, l.ln1g, l.ln1b, nullptr, x1, ldx1, sv ? l.mu1 : nullptr, sv ? l.rs1 : nullptr, M, D, c->c.ln_eps, s));
         }
-        if (lo) {
+        if (lo_qkv) {
             Prof p(c, 4, s);
-            HIP_TRY(launch_lora_skinny(x1, ldx1, 0, 0, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
+            const int xoff[3] = {0, 0, 0};
+            HIP_TRY(launch_lora_skinny(x1, ldx1, xoff, c->nqkv, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
         // TTL_POOLED_LAST_LAYER=0: run the last layer densely (A/B and the equivalence test)
         static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
@@ -605,7 +632,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             // 155 of the 2263 GFLOP of a 64-view image forward disappear.
             const int* map = c->text ? c->poolrows : nullptr;
             const long long pitch = map ? 1 : T;                  // row pitch multiplier when addressing by stride
-            const int Kq = lo ? D + 64 : D;
+            const int Kq = lo_qkv ? D + c->ext : D;
             {
                 GemmArgs a = {};   // K and V for all tokens: rows D..3D of the [3D][ldw] weight image
                 a.A = x1; a.lda = ldx1; a.B = l.wqkv + (size_t)D * c->ldw; a.ldb = c->ldw; a.M = M; a.N = 2 * D; a.K = Kq;
@@ -620,12 +647,17 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             }
             {
                 Prof p(c, 1, s);
-                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s, c->text ? c->pool : nullptr, causal));
+                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, ldat, sv ? l.lse : nullptr, n, T, H, s, c->text ? c->pool : nullptr, causal));
+            }
+            if (lo_o) {   // out_proj adapter: U_o = s * attn * A_o^T into the extension columns of the pooled rows
+                Prof p(c, 4, s);
+                const int xoff[3] = {0, 0, 0};
+                HIP_TRY(launch_lora_skinny(att, pitch * ldat, xoff, 1, l.acat_o, D, c->r, c->scaling, att + D, pitch * ldat, n, s, map));
             }
             float* h_mid = tr ? l.h_mid : h_in;
             {
                 GemmArgs a = {};
-                a.A = att; a.lda = (int)(pitch * D); a.B = l.wo; a.ldb = D; a.M = n; a.N = D; a.K = D;
+                a.A = att; a.lda = (int)(pitch * ldat); a.B = l.wo; a.ldb = l.ldwo; a.M = n; a.N = D; a.K = lo_o ? D + 64 : D;
                 a.C = h_mid; a.ldc = (int)(pitch * D); a.bias = l.bo; a.resid = h_in; a.ldr = (int)(pitch * D); a.amap = map; a.cmap = map;
                 if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
             }
@@ -653,18 +685,23 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         }
         {
             GemmArgs a = {};
-            a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = lo ? D + 64 : D;
+            a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = lo_qkv ? D + c->ext : D;
             a.C = qkv; a.ldc = 3 * D; a.bias = l.bqkv;
             if ((rc = gemm(c, EPI_OP, a, s))) return rc;
         }
         {
             Prof p(c, 1, s);
-            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, D, sv ? l.lse : nullptr, n, T, H, s, causal));
+            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, ldat, sv ? l.lse : nullptr, n, T, H, s, causal));
+        }
+        if (lo_o) {
+            Prof p(c, 4, s);
+            const int xoff[3] = {0, 0, 0};
+            HIP_TRY(launch_lora_skinny(att, ldat, xoff, 1, l.acat_o, D, c->r, c->scaling, att + D, ldat, M, s));
         }
         float* h_mid = tr ? l.h_mid : h_in;
         {
             GemmArgs a = {};
-            a.A = att; a.lda = D; a.B = l.wo; a.ldb = D; a.M = M; a.N = D; a.K = D;
+            a.A = att; a.lda = ldat; a.B = l.wo; a.ldb = l.ldwo; a.M = M; a.N = D; a.K = lo_o ? D + 64 : D;
             a.C = h_mid; a.ldc = D; a.bias = l.bo; a.resid = h_in; a.ldr = D;
             if ((rc = gemm(c, EPI_RESID_F32, a, s))) return rc;
         }
@@ -765,10 +802,17 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
         HIP_TRY(launch_head_bwd(a, dlogits, c->dcls, c->dcls16, n, s));
     }
     const size_t per = (size_t)r * D;
+    const int ldh = c->ldh;
+    const int zoff[3] = {0, 0, 0};
     const float* dres_cls = nullptr;   // != null: d/d h_mid of the layer above is compact (CLS rows only)
     for (int i = c->L - 1; i >= c->c.layer_lo; --i) {
         Layer& l = c->layers[i];
         const bool first = (i == c->c.layer_lo);
+        const bool lo_qkv = l.lora && c->nqkv > 0, lo_o = l.lora && c->has_o;
+        const int need_dk = (!first || (l.lora && c->sk >= 0)) ? 1 : 0;   // the first trained layer needs dK only for a k_proj adapter
+        float* gl = c->lora_g + (size_t)(i - c->c.layer_lo) * c->ntg * 2 * per;   // this layer's gradients: per target A [r,D], B [D,r]
+        WgradList Lo = {};   // out_proj adapter products (their row count differs in the top layer)
+        int Mo = M;
         if (i == c->L - 1) {
             // ---- top layer: the loss reads the CLS token only, so d/d h_out is non-zero on the n CLS
             // rows: MLP, LN2 and out_proj backward run on a compact [n, .] problem (row pitch T*D / T*F
@@ -807,17 +851,30 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             {
                 Prof p(c, 3, s);
                 HIP_TRY(launch_layernorm_bwd(c->dxc, hmid_rows, mu2, rs2, l.ln2g, c->dcls, c->dhmc, c->dhmc16, n, D, s,
-                                             hmid_pitch, (long long)D, stat_pitch, 0));
+                                             hmid_pitch, (long long)D, stat_pitch, 0, nullptr, ldh));
+            }
+            if (lo_o) {   // out_proj adapter on the pooled rows: dU_o = s * d(h_mid) * B_o into the extension columns
+                Prof p(c, 4, s);
+                HIP_TRY(launch_lora_skinny(c->dhmc16, ldh, zoff, 1, l.btcat_o, D, r, c->scaling, c->dhmc16 + D, ldh, n, s));
+                const op_t* att_rows = l.attn; long long att_pitch = (long long)T * l.ldat;
+                if (pool) {   // text tower: the pooled position differs per prompt -> compact copy of those rows
+                    HIP_TRY(launch_gather_rows_op(l.attn, l.ldat, pool, T, c->att_g, n, l.ldat, s));
+                    att_rows = c->att_g; att_pitch = l.ldat;
+                }
+                float* go = gl + (size_t)c->nqkv * 2 * per;
+                Lo.p[0] = {att_rows + D, att_pitch, c->dhmc16, ldh, go + per, 1};        // dB_o = d(h_mid)^T U_o
+                Lo.p[1] = {c->dhmc16 + D, ldh, att_rows, att_pitch, go, 0};              // dA_o = dU_o^T attn
+                Lo.n = 2; Mo = n;
             }
             {
                 GemmArgs a = {};
-                a.A = c->dhmc16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = n; a.N = D; a.K = D;
+                a.A = c->dhmc16; a.lda = ldh; a.B = l.woT; a.ldb = l.ldwo; a.M = n; a.N = D; a.K = lo_o ? D + 64 : D;
                 a.C = c->doc; a.ldc = D;
                 if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, D, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s,
+                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, l.ldat, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, need_dk, s,
                                                  pool, causal));
             }
             dres_cls = c->dhmc;
@@ -825,7 +882,7 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             // ---- MLP: dg = dh·W2 (∘ gelu'(u)) ; dx2 = du·W1 ; dh_mid = dh + LN2^T(dx2)
             {
                 GemmArgs a = {};
-                a.A = c->dh16; a.lda = D; a.B = l.w2T; a.ldb = D; a.M = M; a.N = F; a.K = D;
+                a.A = c->dh16; a.lda = ldh; a.B = l.w2T; a.ldb = D; a.M = M; a.N = F; a.K = D;
                 a.C = c->dbig; a.ldc = F; a.aux = l.u; a.ldaux = F;
                 if ((rc = gemm(c, EPI_GELU_BWD, a, s))) return rc;
             }
@@ -837,44 +894,64 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             }
             {
                 Prof p(c, 3, s);
-                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_mid, l.mu2, l.rs2, l.ln2g, dh, dh_alt, c->dh16, M, D, s));
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_mid, l.mu2, l.rs2, l.ln2g, dh, dh_alt, c->dh16, M, D, s, 0, 0, 1, 0, nullptr, ldh));
             }
-            // ---- attention output projection: do = dh_mid·Wo
+            if (lo_o) {   // out_proj adapter: dU_o = s * d(h_mid) * B_o into the extension columns of dh16
+                Prof p(c, 4, s);
+                HIP_TRY(launch_lora_skinny(c->dh16, ldh, zoff, 1, l.btcat_o, D, r, c->scaling, c->dh16 + D, ldh, M, s));
+                float* go = gl + (size_t)c->nqkv * 2 * per;
+                Lo.p[0] = {l.attn + D, (long long)l.ldat, c->dh16, (long long)ldh, go + per, 1};   // dB_o = d(h_mid)^T U_o
+                Lo.p[1] = {c->dh16 + D, (long long)ldh, l.attn, (long long)l.ldat, go, 0};         // dA_o = dU_o^T attn
+                Lo.n = 2; Mo = M;
+            }
+            // ---- attention output projection: do = [dh_mid | dU_o]·[Wo | A_o]
             {
                 GemmArgs a = {};
-                a.A = c->dh16; a.lda = D; a.B = l.woT; a.ldb = D; a.M = M; a.N = D; a.K = D;
-                a.C = c->dattn; a.ldc = D;
+                a.A = c->dh16; a.lda = ldh; a.B = l.woT; a.ldb = l.ldwo; a.M = M; a.N = D; a.K = lo_o ? D + 64 : D;
+                a.C = c->dattn; a.ldc = l.ldat;   // attention backward reads out and d(out) with one pitch
                 if ((rc = gemm(c, EPI_OP, a, s))) return rc;
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, D, l.lse, c->dqkv, c->ldwt, n, T, H, first ? 0 : 1, s, causal));
+                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, l.ldat, l.lse, c->dqkv, c->ldwt, n, T, H, need_dk, s, causal));
             }
             dres_cls = nullptr;
         }
         float* dhm = dh_alt;  // d/d h_mid (dense layers)
-        // ---- LoRA: dU = s·[dq·B_q | dv·B_v] ; dA, dB   (layers above layer_hi carry no trainable adapters)
+        // ---- LoRA: dU_t = s·d_t·B_t ; dA_t = dU_t^T x, dB_t = d_t^T U_t   (layers above layer_hi carry no trainable adapters)
         if (l.lora) {
             Prof p(c, 4, s);
-            HIP_TRY(launch_lora_skinny(c->dqkv, c->ldwt, 0, 2 * D, l.btcat, D, r, c->scaling, c->dqkv + 3 * D, c->ldwt, M, s));
-            float* g = c->lora_g + (size_t)(i - c->c.layer_lo) * 4 * per;
-            HIP_TRY(launch_lora_wgrad(l.x1ext, c->ldx, c->dqkv, c->ldwt, M, D, r, c->wg_partial, g, g + per, g + 2 * per, g + 3 * per, s,
-                                      c->sc.f, c->sc.i));
+            WgradList Lq = {};
+            if (lo_qkv) {
+                int xoff[3], k = 0;
+                if (c->sq >= 0) xoff[k++] = 0;
+                if (c->sk >= 0) xoff[k++] = D;
+                if (c->sv >= 0) xoff[k++] = 2 * D;
+                HIP_TRY(launch_lora_skinny(c->dqkv, c->ldwt, xoff, c->nqkv, l.btcat, D, r, c->scaling, c->dqkv + 3 * D, c->ldwt, M, s));
+                for (int j = 0; j < c->nqkv; ++j) {
+                    float* gA = gl + (size_t)j * 2 * per;
+                    Lq.p[Lq.n++] = {l.x1ext + D + j * r, (long long)c->ldx, c->dqkv + xoff[j], (long long)c->ldwt, gA + per, 1};   // dB_t
+                    Lq.p[Lq.n++] = {c->dqkv + 3 * D + j * r, (long long)c->ldwt, l.x1ext, (long long)c->ldx, gA, 0};               // dA_t
+                }
+            }
+            if (Lo.n && Mo == M) { Lq.p[Lq.n++] = Lo.p[0]; Lq.p[Lq.n++] = Lo.p[1]; Lo.n = 0; }   // same row count: one launch
+            if (Lq.n) HIP_TRY(launch_lora_wgrad(Lq, M, D, r, c->wg_partial, s, c->sc.f, c->sc.i));
+            if (Lo.n) HIP_TRY(launch_lora_wgrad(Lo, Mo, D, r, c->wg_partial + (size_t)Lq.n * lora_wgrad_chunks(M) * r * D, s, c->sc.f, c->sc.i));
         }
         if (first) break;
         // ---- dx1 = [dq dk dv | dU]·[Wqkv | A]  ; dh_in = dh_mid + LN1^T(dx1)
         {
             GemmArgs a = {};
-            a.A = c->dqkv; a.lda = c->ldwt; a.B = l.wqkvT; a.ldb = c->ldwt; a.M = M; a.N = D; a.K = l.lora ? c->ldwt : 3 * D;
+            a.A = c->dqkv; a.lda = c->ldwt; a.B = l.wqkvT; a.ldb = c->ldwt; a.M = M; a.N = D; a.K = lo_qkv ? c->ldwt : 3 * D;
             a.C = c->dx; a.ldc = D;
             if ((rc = gemm(c, EPI_F32, a, s))) return rc;
         }
         {
             Prof p(c, 3, s);
             if (dres_cls)
-                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dres_cls, dh, c->dh16, M, D, s, 0, 0, 1, T, pool));
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dres_cls, dh, c->dh16, M, D, s, 0, 0, 1, T, pool, ldh));
             else
-                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s));
+                HIP_TRY(launch_layernorm_bwd(c->dx, l.h_in, l.mu1, l.rs1, l.ln1g, dhm, dh, c->dh16, M, D, s, 0, 0, 1, 0, nullptr, ldh));
         }
         // dh now holds d/d h_in of layer i == d/d h_out of layer i-1
     }
@@ -1156,7 +1233,7 @@ int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t by
         else if (nm == "h_mid") { src = l.h_mid; have = M * D * 4; }
         else if (nm == "h_out") { src = c->h_out[layer - c->c.layer_lo]; have = M * D * 4; }
         else if (nm == "qkv") { src = l.qkv; have = M * 3 * D * 2; }
-        else if (nm == "attn_out") { src = l.attn; have = M * D * 2; }
+        else if (nm == "attn_out") { src = l.attn; have = M * l.ldat * 2; }
         else if (nm == "x1") { src = l.x1ext; have = M * c->ldx * 2; }
         else if (nm == "u") { src = l.u; have = M * F * 2; }
         else if (nm == "lse") { src = l.lse; have = (size_t)c->saved_n * c->H * c->T * 4; }

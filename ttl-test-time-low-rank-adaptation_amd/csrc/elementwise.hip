@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ o32, op_t* __restrict__ o16, int rows, int D,
                                                      long long xs, long long os, int stat_stride, int dres_T,
-                                                     const int* __restrict__ pool) {
+                                                     const int* __restrict__ pool, long long os16) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (o16) *(u32x2*)(o16 + (size_t)row * os + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+            if (o16) *(u32x2*)(o16 + (size_t)row * os16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
         }
     }
 }
@@ -301,11 +301,11 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, op_t* out_bf16, int rows,
                                 int D, hipStream_t s, long long x_stride, long long o_stride, int stat_stride,
-                                int dres_T, const int* pool) {
+                                int dres_T, const int* pool, long long ld_bf16) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
                        out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D,
-                       stat_stride, dres_T, pool);
+                       stat_stride, dres_T, pool, ld_bf16 ? ld_bf16 : (o_stride ? o_stride : (long long)D));
     return hipGetLastError();
 }
 

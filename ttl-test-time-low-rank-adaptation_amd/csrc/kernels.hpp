@@ -65,7 +65,8 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* out_f32, op_t* out_bf16,
                                 int rows, int D, hipStream_t s, long long x_stride = 0, long long o_stride = 0,
-                                int stat_stride = 1, int dres_T = 0, const int* pool = nullptr);
+                                int stat_stride = 1, int dres_T = 0, const int* pool = nullptr,
+                                long long ld_bf16 = 0 /* pitch of out_bf16 when it differs from o_stride (K-extended operand buffers) */);
 // text tower: h[row][:] = tok[ids[row]][:] + pos[row % T][:]   (fp32, like HF CLIPTextEmbeddings)
 hipError_t launch_text_embed(const int* ids, const float* tok, const float* pos, float* h, int rows, int T, int D, hipStream_t s);
 // dst[v][0..cols) = src[(v*T + pool[v]) * ld + 0..cols): the pooled row of every sequence, compact
@@ -144,25 +145,28 @@ hipError_t launch_scaler_reset_step(ScalerState st, hipStream_t s);
 hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- LoRA (lora.hip)
-// Refresh the bf16 images derived from the fp32 LoRA params of ONE layer:
-//   wqkv_ext [3D][ldw]: cols D..D+r of rows 0..D = B_q ; cols D+r..D+2r of rows 2D..3D = B_v
-//   wqkvT_ext [D][ldwt]: cols 3D..3D+r = A_q^T ; cols 3D+r..3D+2r = A_v^T
-//   a_cat [2r][D] = [A_q; A_v] ;  bT_cat [2r][D] = [B_q^T; B_v^T]
-hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av, const float* Bv, int D, int r,
-                               op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat,
-                               op_t* bT_cat, hipStream_t s);
-// out[m][c] = bf16(scale * sum_k X[m][xoff(c) + k] * Wcat[c][k]),  c in [0,2r), k in [0,D)
-//   xoff(c) = (c < r) ? xoff_q : xoff_v   (lora_down: both 0; dU: dq at 0, dv at 2D)
-hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, int r,
-                              float scale, op_t* out, int ldo, int M, hipStream_t s);
-// LoRA weight gradients of one layer from saved activations:
-//   dB_q = dq^T Us_q, dB_v = dv^T Us_v, dA_q = dU_q^T x1, dA_v = dU_v^T x1      (Us = s*x1*A^T)
-// x1ext [M][ldx]: cols 0..D = x1, cols D..D+2r = Us ; dqkv [M][ldd]: dq | dk | dv | dU_q dU_v
-// partial: fp32 scratch [nchunk][4][r][D]; grads written to gAq [r,D], gBq [D,r], gAv, gBv
-// scaler_f / scaler_i (ScalerState arrays, may be null): the gradients are divided by the loss scale scaler_f[0] and
-// any non-finite value sets scaler_i[0] (found_inf)
-hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r,
-                             float* partial, float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s,
+// fp32 LoRA parameters of ONE layer, in the order q_proj, k_proj, v_proj, out_proj (null = the projection has no adapter;
+// the reference ships q and v, clip/custom_clip.py:586)
+struct LoraPtrs { const float* A[4]; const float* B[4]; };
+// Refresh the bf16 images derived from them (slot k = position of a q/k/v adapter among the enabled ones):
+//   wqkv_ext [3D][ldw]:  cols D + k*r.. of rows t*D.. = B_t ;  wqkvT_ext [D][ldwt]: cols 3D + k*r.. = A_t^T
+//   a_cat [nqkv*r][D] = rows of A_t ;  bT_cat [nqkv*r][D] = rows of B_t^T
+//   out_proj: wo_ext [D][ldwo] cols D.. = B_o ; woT_ext [D][ldwo] cols D.. = A_o^T ; acat_o [r][D] = A_o ; btcat_o [r][D] = B_o^T
+hipError_t launch_lora_refresh(const LoraPtrs& P, int D, int r, op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat,
+                               op_t* bT_cat, op_t* wo_ext, op_t* woT_ext, int ldwo, op_t* acat_o, op_t* btcat_o, hipStream_t s);
+// out[m][k*r + c] = operand(scale * sum_d X[m][xoff[k] + d] * Wcat[k*r + c][d]),  k in [0,ntg), c in [0,r), d in [0,D)
+//   (lora_down: every xoff 0; dU: dq at 0, dk at D, dv at 2D).  rowmap (optional): row m lives at physical row rowmap[m].
+hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int ntg, const op_t* Wcat, int D, int r, float scale,
+                              op_t* out, long long ldo, int M, hipStream_t s, const int* rowmap = nullptr);
+// LoRA weight gradients from saved activations, as a list of products  out = S^T · G  over M rows:
+//   dB_t = d_t^T Us_t (S = Us_t = s*x*A_t^T [M][r], G = d_t [M][D], stored transposed [D][r]);  dA_t = dU_t^T x (S = dU_t, G = x).
+// Pitches in elements (a pitch of T*ld walks the pooled row of every sequence).  partial: fp32 scratch [n][nchunk][r][D].
+// scaler_f / scaler_i (ScalerState arrays, may be null): the gradients are divided by the loss scale scaler_f[0] and any
+// non-finite value sets scaler_i[0] (found_inf).
+constexpr int WGRAD_MAX = 8;
+struct WgradProd { const op_t* S; long long lds; const op_t* G; long long ldg; float* out; int transpose; };
+struct WgradList { WgradProd p[WGRAD_MAX]; int n; };
+hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* partial, hipStream_t s,
                              const float* scaler_f = nullptr, int* scaler_i = nullptr);
 int lora_wgrad_chunks(int M);
 

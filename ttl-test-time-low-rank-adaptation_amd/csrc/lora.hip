@@ -15,41 +15,51 @@
 
 namespace {
 
-__global__ void refresh_kernel(const float* __restrict__ Aq, const float* __restrict__ Bq, const float* __restrict__ Av,
-                               const float* __restrict__ Bv, int D, int r, op_t* __restrict__ wext, int ldw,
-                               op_t* __restrict__ wtext, int ldwt, op_t* __restrict__ acat,
-                               op_t* __restrict__ btcat) {
+// bf16 images of one layer's adapters.  q/k/v adapters (slot k = position among the enabled ones): B_t -> columns D + k*r of rows
+// t*D.. of wqkv_ext (forward K-extension) and row block k of btcat (= B_t^T); A_t -> row block k of acat and columns 3D + k*r of
+// wqkvT_ext (dgrad K-extension).  out_proj adapter: B_o -> columns D.. of wo_ext, A_o^T -> columns D.. of woT_ext, plus
+// acat_o = A_o and btcat_o = B_o^T for the skinny products.
+__global__ void refresh_kernel(LoraPtrs P, int3 slot /* of q, k, v; -1 = none */, int D, int r, op_t* __restrict__ wext, int ldw,
+                               op_t* __restrict__ wtext, int ldwt, op_t* __restrict__ acat, op_t* __restrict__ btcat,
+                               op_t* __restrict__ woext, op_t* __restrict__ wotext, int ldwo, op_t* __restrict__ acat_o,
+                               op_t* __restrict__ btcat_o) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D * r) return;
-    {   // B side: i = n*r + j
-        int n = i / r, j = i - n * r;
-        op_t bq = f32_to_op(Bq[i]), bv = f32_to_op(Bv[i]);
-        wext[(size_t)n * ldw + D + j] = bq;
-        wext[(size_t)(2 * D + n) * ldw + D + r + j] = bv;
-        btcat[(size_t)j * D + n] = bq;
-        btcat[(size_t)(r + j) * D + n] = bv;
+    const int nB = i / r, jB = i - nB * r;      // B side: i = n*r + j
+    const int jA = i / D, dA = i - jA * D;      // A side: i = j*D + d
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = t == 0 ? slot.x : t == 1 ? slot.y : slot.z;
+        if (k < 0) continue;
+        const op_t b = f32_to_op(P.B[t][i]), a = f32_to_op(P.A[t][i]);
+        wext[(size_t)(t * D + nB) * ldw + D + k * r + jB] = b;
+        btcat[(size_t)(k * r + jB) * D + nB] = b;
+        acat[(size_t)(k * r + jA) * D + dA] = a;
+        wtext[(size_t)dA * ldwt + 3 * D + k * r + jA] = a;
     }
-    {   // A side: i = j*D + d
-        int j = i / D, d = i - j * D;
-        op_t aq = f32_to_op(Aq[i]), av = f32_to_op(Av[i]);
-        acat[(size_t)j * D + d] = aq;
-        acat[(size_t)(r + j) * D + d] = av;
-        wtext[(size_t)d * ldwt + 3 * D + j] = aq;
-        wtext[(size_t)d * ldwt + 3 * D + r + j] = av;
+    if (P.A[3]) {
+        const op_t b = f32_to_op(P.B[3][i]), a = f32_to_op(P.A[3][i]);
+        woext[(size_t)nB * ldwo + D + jB] = b;
+        btcat_o[(size_t)jB * D + nB] = b;
+        acat_o[(size_t)jA * D + dA] = a;
+        wotext[(size_t)dA * ldwo + D + jA] = a;
     }
 }
 
-// One wave: 16 rows of X times all 2r columns.  MFMA A operand = Wcat rows (output row = column
-// c of the result), B operand = X rows (output column = token) -> each lane ends with 4
-// consecutive result columns of one token: one 8-byte store.  The kernel is pure latency (a
-// few hundred waves, each a serial K loop), so ALL of a wave's X fragments are requested up
-// front (KS x 16 B per lane in flight) and Wcat is staged once per workgroup in LDS.
-template <int NCG, int KS>   // KS = D / 32 k-steps
-__global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X, int ldx, int xoff_q, int xoff_v,
-                                                     const op_t* __restrict__ W, int D, float scale,
-                                                     op_t* __restrict__ out, int ldo, int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // Wcat [16*NCG][D] operand type, rows padded by 16 B
+// One wave: 16 rows of X times the r columns of ONE adapter (blockIdx.y = slot of the adapter).  MFMA A operand = Wcat rows
+// (output row = column c of the result), B operand = X rows (output column = token) -> each lane ends with 4 consecutive
+// result columns of one token: one 8-byte store.  The kernel is pure latency (a few hundred waves, each a serial K loop), so
+// ALL of a wave's X fragments are requested up front (KS x 16 B per lane in flight) and the adapter's rows of Wcat are staged
+// once per workgroup in LDS.  rowmap (optional): logical row m lives at physical row rowmap[m] of X and out.
+template <int NCG, int KS>   // NCG = r / 16 column groups, KS = D / 32 k-steps
+__global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X, long long ldx, int3 xoff,
+                                                     const op_t* __restrict__ Wcat, int D, float scale,
+                                                     op_t* __restrict__ out, long long ldo, int M, const int* __restrict__ rowmap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // W [16*NCG][D] operand type, rows padded by 16 B
     const int tid = threadIdx.x, lane = tid & 63;
+    const int t = blockIdx.y;
+    const int xo = t == 0 ? xoff.x : t == 1 ? xoff.y : xoff.z;
+    const op_t* W = Wcat + (size_t)t * 16 * NCG * D;
     const int rowb = D * 2 + 16;
     for (int q = tid; q < 16 * NCG * (D / 8); q += 256) {
         int r = q / (D / 8), c = q - r * (D / 8);
@@ -58,16 +68,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X,
     const int m0 = (blockIdx.x * 4 + (tid >> 6)) * 16;
     const int li = lane & 15, lg = lane >> 4;
     const int row = min(m0 + li, M - 1);
-    const bool same = (xoff_q == xoff_v);
-    const op_t* xq = X + (size_t)row * ldx + xoff_q + 8 * lg;
-    const op_t* xv = X + (size_t)row * ldx + xoff_v + 8 * lg;
-    opx8 fq[KS], fv[KS];
+    const long long prow = rowmap ? rowmap[row] : row;
+    const op_t* x = X + prow * ldx + xo + 8 * lg;
+    opx8 f[KS];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) fq[k] = *(const opx8*)(xq + 32 * k);
-    if (!same) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) fv[k] = *(const opx8*)(xv + 32 * k);
-    }
+    for (int k = 0; k < KS; ++k) f[k] = *(const opx8*)(x + 32 * k);
     __syncthreads();
     f32x4 acc[NCG];
 #pragma unroll
@@ -77,13 +82,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X,
 #pragma unroll
         for (int c = 0; c < NCG; ++c) {
             opx8 w = *(const opx8*)(smem + (c * 16 + li) * rowb + (32 * k + 8 * lg) * 2);
-            acc[c] = MFMA16(w, (c < NCG / 2 || same) ? fq[k] : fv[k], acc[c], 0, 0, 0);
+            acc[c] = MFMA16(w, f[k], acc[c], 0, 0, 0);
         }
     }
     if (m0 < M && m0 + li < M) {
 #pragma unroll
         for (int c = 0; c < NCG; ++c)
-            *(u32x2*)(out + (size_t)(m0 + li) * ldo + c * 16 + 4 * lg) =
+            *(u32x2*)(out + prow * ldo + (t * NCG + c) * 16 + 4 * lg) =
                 u32x2{pack_op2(acc[c][0] * scale, acc[c][1] * scale), pack_op2(acc[c][2] * scale, acc[c][3] * scale)};
     }
 }
@@ -95,31 +100,27 @@ constexpr int WG_BN = 128;   // result columns per block
 __device__ __forceinline__ int wg_u(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <int R>
-__global__ __launch_bounds__(256) void wgrad_kernel(const op_t* __restrict__ x1ext, int ldx, const op_t* __restrict__ dqkv,
-                                                    int ldd, int M, int D, float* __restrict__ partial, int nch) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, int D, float* __restrict__ partial, int nch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sG = smem;                       // [256][128] bf16, 256-B rows, 16-B chunk c at c ^ (u(row) << 1)
     char* sS = smem + WG_CH * WG_BN * 2;   // [256][R] bf16, plain
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch = blockIdx.x, cb = blockIdx.y, prod = blockIdx.z;
     const int m0 = ch * WG_CH, n0 = cb * WG_BN;
-    // operands of this product
-    const op_t* S; int lds_; const op_t* G; int ldg;
-    if (prod == 0)      { S = x1ext + D;           lds_ = ldx; G = dqkv;          ldg = ldd; }  // dB_q^T = Us_q^T dq
-    else if (prod == 1) { S = x1ext + D + R;       lds_ = ldx; G = dqkv + 2 * D;  ldg = ldd; }  // dB_v^T = Us_v^T dv
-    else if (prod == 2) { S = dqkv + 3 * D;        lds_ = ldd; G = x1ext;         ldg = ldx; }  // dA_q = dU_q^T x1
-    else                { S = dqkv + 3 * D + R;    lds_ = ldd; G = x1ext;         ldg = ldx; }  // dA_v = dU_v^T x1
+    // operands of this product: result [R][D] = S^T · G over the M rows
+    const op_t* S = L.p[prod].S; const long long lds_ = L.p[prod].lds;
+    const op_t* G = L.p[prod].G; const long long ldg = L.p[prod].ldg;
     // stage G tile: 256 rows x 16 chunks of 16 B
     for (int q = tid; q < WG_CH * 16; q += 256) {
         int r = q >> 4, c = q & 15;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (m0 + r < M) v = *(const u32x4*)(G + (size_t)(m0 + r) * ldg + n0 + c * 8);
+        if (m0 + r < M) v = *(const u32x4*)(G + (long long)(m0 + r) * ldg + n0 + c * 8);
         *(u32x4*)(sG + r * 256 + ((c ^ (wg_u(r) << 1)) << 4)) = v;
     }
     for (int q = tid; q < WG_CH * (R / 8); q += 256) {
         int r = q / (R / 8), c = q - r * (R / 8);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (m0 + r < M) v = *(const u32x4*)(S + (size_t)(m0 + r) * lds_ + c * 8);
+        if (m0 + r < M) v = *(const u32x4*)(S + (long long)(m0 + r) * lds_ + c * 8);
         *(u32x4*)(sS + r * (R * 2) + (c << 4)) = v;
     }
     __syncthreads();
@@ -165,9 +166,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const op_t* __restrict__ x1e
 
 // 64 outputs x 4 chunk-slices per block: slice q sums chunks q, q+4, ... in order, the four slice sums are added in a
 // fixed order -> deterministic; one thread walking all ~50 chunks serially left the 9.8 MB read latency-bound (16 us)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, int D, int r,
-                                                           float* __restrict__ gAq, float* __restrict__ gBq,
-                                                           float* __restrict__ gAv, float* __restrict__ gBv,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, int D, int r, const WgradList L,
                                                            const float* __restrict__ scaler_f, int* __restrict__ scaler_i) {
     __shared__ float part[4][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
@@ -187,67 +186,67 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (scaler_f) s *= scaler_f[1];
     if (scaler_i && !isfinite(s)) atomicOr(scaler_i, 1);
     int j = i / D, d = i - j * D;
-    if (prod == 0) gBq[(size_t)d * r + j] = s;
-    else if (prod == 1) gBv[(size_t)d * r + j] = s;
-    else if (prod == 2) gAq[i] = s;
-    else gAv[i] = s;
+    float* out = L.p[prod].out;
+    if (L.p[prod].transpose) out[(size_t)d * r + j] = s;   // dB [D][r]
+    else out[i] = s;                                        // dA [r][D]
 }
 
 }  // namespace
 
-hipError_t launch_lora_refresh(const float* Aq, const float* Bq, const float* Av, const float* Bv, int D, int r,
-                               op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat, op_t* bT_cat,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(refresh_kernel, dim3((D * r + 255) / 256), dim3(256), 0, s, Aq, Bq, Av, Bv, D, r, wqkv_ext, ldw,
-                       wqkvT_ext, ldwt, a_cat, bT_cat);
+hipError_t launch_lora_refresh(const LoraPtrs& P, int D, int r, op_t* wqkv_ext, int ldw, op_t* wqkvT_ext, int ldwt, op_t* a_cat,
+                               op_t* bT_cat, op_t* wo_ext, op_t* woT_ext, int ldwo, op_t* acat_o, op_t* btcat_o, hipStream_t s) {
+    int3 slot; int k = 0;
+    slot.x = P.A[0] ? k++ : -1; slot.y = P.A[1] ? k++ : -1; slot.z = P.A[2] ? k++ : -1;
+    hipLaunchKernelGGL(refresh_kernel, dim3((D * r + 255) / 256), dim3(256), 0, s, P, slot, D, r, wqkv_ext, ldw, wqkvT_ext, ldwt, a_cat,
+                       bT_cat, wo_ext, woT_ext, ldwo, acat_o, btcat_o);
     return hipGetLastError();
 }
 
 template <int NCG, int KS>
-static hipError_t skinny_launch(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, float scale, op_t* out,
-                                int ldo, int M, hipStream_t s) {
+static hipError_t skinny_launch(const op_t* X, long long ldx, int3 xoff, int ntg, const op_t* W, int D, float scale, op_t* out,
+                                long long ldo, int M, hipStream_t s, const int* rowmap) {
     const int smem = 16 * NCG * (D * 2 + 16);
-    static bool done = false;
-    if (!done) {
+    static std::atomic<bool> done{false};
+    if (!done.load()) {
         hipError_t e = hipFuncSetAttribute((const void*)skinny_kernel<NCG, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        done = true;
+        done.store(true);
     }
-    hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 63) / 64), dim3(256), smem, s, X, ldx, xoff_q, xoff_v, Wcat, D, scale, out,
-                       ldo, M);
+    hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 63) / 64, ntg), dim3(256), smem, s, X, ldx, xoff, W, D, scale, out, ldo, M, rowmap);
     return hipGetLastError();
 }
 
-hipError_t launch_lora_skinny(const op_t* X, int ldx, int xoff_q, int xoff_v, const op_t* Wcat, int D, int r,
-                              float scale, op_t* out, int ldo, int M, hipStream_t s) {
-    const int ncg = 2 * r / 16, ks = D / 32;
-#define SK(N_, K_) if (ncg == N_ && ks == K_ && D % 32 == 0) return skinny_launch<N_, K_>(X, ldx, xoff_q, xoff_v, Wcat, D, scale, out, ldo, M, s)
-    SK(2, 24); SK(4, 24);      // ViT-B/16, r = 16 / 32
-    SK(2, 32); SK(4, 32);      // ViT-L/14
-    SK(2, 16); SK(4, 16);      // text tower of ViT-B/16 (D = 512)
-    SK(2, 4);  SK(4, 4);       // reduced test geometry (D = 128)
+hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int ntg, const op_t* Wcat, int D, int r, float scale,
+                              op_t* out, long long ldo, int M, hipStream_t s, const int* rowmap) {
+    if (ntg < 1 || ntg > 3) return hipErrorInvalidValue;
+    const int3 xo = {xoff[0], ntg > 1 ? xoff[1] : 0, ntg > 2 ? xoff[2] : 0};
+    const int ncg = r / 16, ks = D / 32;
+#define SK(N_, K_) if (ncg == N_ && ks == K_ && D % 32 == 0) return skinny_launch<N_, K_>(X, ldx, xo, ntg, Wcat, D, scale, out, ldo, M, s, rowmap)
+    SK(1, 24); SK(2, 24);      // ViT-B/16, r = 16 / 32
+    SK(1, 32); SK(2, 32);      // ViT-L/14
+    SK(1, 16); SK(2, 16);      // text tower of ViT-B/16 (D = 512)
+    SK(1, 4);  SK(2, 4);       // reduced test geometry (D = 128)
 #undef SK
     return hipErrorInvalidValue;
 }
 
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
 
-hipError_t launch_lora_wgrad(const op_t* x1ext, int ldx, const op_t* dqkv, int ldd, int M, int D, int r, float* partial,
-                             float* gAq, float* gBq, float* gAv, float* gBv, hipStream_t s, const float* scaler_f, int* scaler_i) {
-    if (D % WG_BN) return hipErrorInvalidValue;
+hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* partial, hipStream_t s, const float* scaler_f, int* scaler_i) {
+    if (D % WG_BN || L.n < 1 || L.n > WGRAD_MAX) return hipErrorInvalidValue;
     const int nch = lora_wgrad_chunks(M);
-    dim3 grid(nch, D / WG_BN, 4);
+    dim3 grid(nch, D / WG_BN, L.n);
     if (r == 16) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 16 * 2;
         static std::atomic<bool> done{false};
         if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
-        hipLaunchKernelGGL((wgrad_kernel<16>), grid, dim3(256), SMEM, s, x1ext, ldx, dqkv, ldd, M, D, partial, nch);
+        hipLaunchKernelGGL((wgrad_kernel<16>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
     } else if (r == 32) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 32 * 2;
         static std::atomic<bool> done{false};
         if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
-        hipLaunchKernelGGL((wgrad_kernel<32>), grid, dim3(256), SMEM, s, x1ext, ldx, dqkv, ldd, M, D, partial, nch);
+        hipLaunchKernelGGL((wgrad_kernel<32>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
     } else return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, 4), dim3(256), 0, s, partial, nch, D, r, gAq, gBq, gAv, gBv, scaler_f, scaler_i);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);
     return hipGetLastError();
 }

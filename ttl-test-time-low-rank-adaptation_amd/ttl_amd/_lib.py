@@ -33,7 +33,7 @@ class ttl_config(C.Structure):
                 ("mlp", C.c_int), ("layers", C.c_int), ("embed", C.c_int), ("rank", C.c_int),
                 ("lora_alpha", C.c_float), ("layer_lo", C.c_int), ("layer_hi", C.c_int), ("ln_eps", C.c_float),
                 ("max_views", C.c_int), ("max_classes", C.c_int), ("tower", C.c_int), ("context_length", C.c_int),
-                ("vocab_size", C.c_int)]
+                ("vocab_size", C.c_int), ("lora_targets", C.c_int)]
 
 
 class ttl_episode_args(C.Structure):

@@ -24,6 +24,9 @@ class VitConfig:
     # first / last encoder layer whose q/v adapters train (ttl.py:159-161, --layer_range)
     layer_lo: int = 9
     layer_hi: int = 11
+    # attention projections that carry an adapter.  The reference ships ["q_proj", "v_proj"] (clip/custom_clip.py:586, the k
+    # slots of LoRA_AB are commented out at :181-182,216-217); k_proj / out_proj are what BASELINE.json's north_star adds.
+    lora_targets: tuple = ("q_proj", "v_proj")
 
     @property
     def grid(self) -> int:
@@ -69,6 +72,7 @@ class TextConfig:
     lora_alpha: float = 32.0
     layer_lo: int = 9
     layer_hi: int = 11
+    lora_targets: tuple = ("q_proj", "v_proj")
 
     @property
     def tokens(self) -> int:
@@ -107,6 +111,22 @@ TEXT_ARCHS = {"ViT-B/16": TEXT_B16, "ViT-B/32": TEXT_B16, "ViT-L/14": TEXT_L14, 
 
 ARCHS = {"ViT-B/16": VIT_B16, "ViT-B/32": VIT_B32, "ViT-L/14": VIT_L14, "tiny": VIT_TINY, "tiny197": VIT_TINY197, "tiny_mid": VIT_TINY_MID,
          "tiny_all": VIT_TINY_ALL}
+
+
+LORA_TARGET_ORDER = ("q_proj", "k_proj", "v_proj", "out_proj")      # order of the parameter groups inside a layer
+LORA_TARGET_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8}
+
+
+def ordered_targets(cfg):
+    """cfg.lora_targets in canonical order (q, k, v, out)."""
+    bad = set(cfg.lora_targets) - set(LORA_TARGET_ORDER)
+    if bad or not cfg.lora_targets:
+        raise ValueError(f"lora_targets must be a non-empty subset of {LORA_TARGET_ORDER}, got {cfg.lora_targets}")
+    return tuple(t for t in LORA_TARGET_ORDER if t in cfg.lora_targets)
+
+
+def targets_mask(cfg):
+    return sum(LORA_TARGET_BITS[t] for t in ordered_targets(cfg))
 
 
 def get_config(arch: str) -> VitConfig:

@@ -53,22 +53,26 @@ class _LoRAProj(nn.Module):
 
 
 class _SelfAttn(nn.Module):
-    def __init__(self, dim, rank, alpha):
+    def __init__(self, dim, rank, alpha, targets=("q_proj", "v_proj")):
         super().__init__()
-        self.q_proj = _LoRAProj(dim, rank, alpha)
-        self.v_proj = _LoRAProj(dim, rank, alpha)
+        # peft wraps the modules named in LoraConfig.target_modules (clip/custom_clip.py:586: q_proj, v_proj); k_proj and
+        # out_proj adapters exist when the model is built with target_modules naming them.  Canonical order q, k, v, out.
+        for t in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            if t in targets:
+                setattr(self, t, _LoRAProj(dim, rank, alpha))
+        self.lora_targets = tuple(t for t in ("q_proj", "k_proj", "v_proj", "out_proj") if t in targets)
 
 
 class _EncoderLayer(nn.Module):
-    def __init__(self, dim, rank, alpha):
+    def __init__(self, dim, rank, alpha, targets=("q_proj", "v_proj")):
         super().__init__()
-        self.self_attn = _SelfAttn(dim, rank, alpha)
+        self.self_attn = _SelfAttn(dim, rank, alpha, targets)
 
 
 class _Encoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
-        self.layers = nn.ModuleList([_EncoderLayer(cfg.width, cfg.rank, cfg.lora_alpha) for _ in range(cfg.layers)])
+        self.layers = nn.ModuleList([_EncoderLayer(cfg.width, cfg.rank, cfg.lora_alpha, tuple(cfg.lora_targets)) for _ in range(cfg.layers)])
 
 
 class _VisionModel(nn.Module):
@@ -265,26 +269,26 @@ class LoRA_AB:
         raise NotImplementedError(f"lora_encoder={self.lora_encoder!r}: prompt tuning is out of scope (SURVEY.md §8)")
 
     def initialize_layer_weights(self, layer, fn):
-        aq = layer.self_attn.q_proj.lora_A.default.weight
-        bq = layer.self_attn.q_proj.lora_B.default.weight
-        av = layer.self_attn.v_proj.lora_A.default.weight
-        bv = layer.self_attn.v_proj.lora_B.default.weight
+        projs = [getattr(layer.self_attn, t) for t in layer.self_attn.lora_targets]      # reference: q_proj, v_proj
         # reference: `if self.init_method != (None or 'pretrained')` == `!= 'pretrained'` (custom_clip.py:184)
         if self.init_method != 'pretrained':
             with torch.no_grad():
-                fn(aq)   # q first, then v, layer 0..L-1: the reference's RNG draw order
-                fn(av)
-        self.init_weights.append((aq.detach().clone(), bq.detach().clone(), av.detach().clone(), bv.detach().clone()))
+                for pj in projs:     # q first, then v, layer 0..L-1: the reference's RNG draw order (k / out slot in canonically)
+                    fn(pj.lora_A.default.weight)
+        snap = []
+        for pj in projs:
+            snap += [pj.lora_A.default.weight.detach().clone(), pj.lora_B.default.weight.detach().clone()]
+        self.init_weights.append(tuple(snap))      # (aq, bq, av, bv) for the reference's targets
 
     def reset(self):
         layers = self._layers()
         for i, layer in enumerate(layers):
             if i in range(self.layer_range[0], self.layer_range[1] + 1):
-                aq, bq, av, bv = self.init_weights[i]
-                layer.self_attn.q_proj.lora_A.default.weight.data.copy_(aq)
-                layer.self_attn.q_proj.lora_B.default.weight.data.copy_(bq)
-                layer.self_attn.v_proj.lora_A.default.weight.data.copy_(av)
-                layer.self_attn.v_proj.lora_B.default.weight.data.copy_(bv)
+                snap = self.init_weights[i]
+                for k, t in enumerate(layer.self_attn.lora_targets):
+                    pj = getattr(layer.self_attn, t)
+                    pj.lora_A.default.weight.data.copy_(snap[2 * k])
+                    pj.lora_B.default.weight.data.copy_(snap[2 * k + 1])
 
 
 # ------------------------------------------------------------------------------- text side
@@ -365,14 +369,17 @@ class ClipTestTimeTuning(nn.Module):
 
     def __init__(self, device, classnames, batch_size, criterion='cosine', arch="ViT-B/16", n_ctx=16, ctx_init=None,
                  ctx_position='end', learned_cls=False, layer_range=[9, 11], init_method=None, lora_encoder='text',
-                 rank=16, max_views=64, max_classes=1000, weight_seed=0, precision="bf16"):
+                 rank=16, max_views=64, max_classes=1000, weight_seed=0, precision="bf16",
+                 target_modules=("q_proj", "v_proj")):
+        """``target_modules``: attention projections that carry an adapter — the reference hard-codes ["q_proj", "v_proj"] in
+        its LoraConfig (clip/custom_clip.py:586); "k_proj" / "out_proj" add the adapters BASELINE.json's north_star names."""
         super().__init__()
         if lora_encoder not in ('image', 'text'):
             raise NotImplementedError(f"lora_encoder={lora_encoder!r}: prompt tuning is out of scope (SURVEY.md §8)")
         self.device = torch.device(f"cuda:{device}" if isinstance(device, int) else device)
         self.lora_encoder = lora_encoder
         cfg = get_config(arch)
-        self.cfg = cfg = cfg.replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1])
+        self.cfg = cfg = cfg.replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1], lora_targets=tuple(target_modules))
         self.layer_range = list(layer_range)
         self.criterion = criterion
         self.precision = precision   # MFMA operand dtype: "bf16" (default) or "fp16" (reference's autocast dtype)
@@ -389,7 +396,8 @@ class ClipTestTimeTuning(nn.Module):
                 p.requires_grad_(False)
             self.LoRA_AB = LoRA_AB(self.image_encoder, layer_range=layer_range, init_method=init_method, lora_encoder=lora_encoder)
         else:
-            self.tcfg = get_text_config(arch).replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1])
+            self.tcfg = get_text_config(arch).replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1],
+                                                      lora_targets=tuple(target_modules))
             self._text_state = getattr(clip_model, "_ttl_text_state", None) or synth.text_weights(self.tcfg, weight_seed)
             self.text_encoder = TextEncoderHIP(self.tcfg)
             object.__setattr__(self.text_encoder, "_owner", self)
@@ -412,8 +420,9 @@ class ClipTestTimeTuning(nn.Module):
         tower = self.image_encoder.vision_model if self.lora_encoder == 'image' else self.text_encoder.text_model
         for i in range(self.layer_range[0], self.layer_range[1] + 1):
             sa = tower.encoder.layers[i].self_attn
-            out += [sa.q_proj.lora_A.default.weight, sa.q_proj.lora_B.default.weight,
-                    sa.v_proj.lora_A.default.weight, sa.v_proj.lora_B.default.weight]
+            for t in sa.lora_targets:            # ttl.py:195-213: q.A, q.B, v.A, v.B (+ k / out in canonical order when configured)
+                pj = getattr(sa, t)
+                out += [pj.lora_A.default.weight, pj.lora_B.default.weight]
         return out
 
     def _ensure_engine(self):

@@ -12,6 +12,11 @@ from . import _lib
 from .config import VitConfig
 
 
+def _targets_mask(cfg):
+    from .config import targets_mask
+    return targets_mask(cfg)
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -43,7 +48,8 @@ class TTLEngine:
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
         self._h = h
-        self.n_lora = (cfg.layer_hi - cfg.layer_lo + 1) * 4 * cfg.rank * cfg.width
+        from .config import ordered_targets
+        self.n_lora = (cfg.layer_hi - cfg.layer_lo + 1) * len(ordered_targets(cfg)) * 2 * cfg.rank * cfg.width
         self.grads = torch.zeros(self.n_lora, dtype=torch.float32, device=self.device)
         self._params = None
         self._keep = []
@@ -51,7 +57,7 @@ class TTLEngine:
     def _make_config(self, cfg):
         return _lib.ttl_config(cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers,
                                cfg.embed, cfg.rank, cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps,
-                               self.max_views, self.max_classes, _lib.TTL_TOWER_IMAGE, 0, 0)
+                               self.max_views, self.max_classes, _lib.TTL_TOWER_IMAGE, 0, 0, _targets_mask(cfg))
 
     def _check(self, rc):
         _lib.check(rc, self.lib)
@@ -301,7 +307,7 @@ class TextTowerEngine(TTLEngine):
     def _make_config(self, cfg):
         return _lib.ttl_config(0, 0, cfg.width, cfg.heads, cfg.mlp, cfg.layers, cfg.embed, cfg.rank, cfg.lora_alpha,
                                cfg.layer_lo, cfg.layer_hi, cfg.ln_eps, self.max_views, self.max_classes,
-                               _lib.TTL_TOWER_TEXT, cfg.context_length, cfg.vocab_size)
+                               _lib.TTL_TOWER_TEXT, cfg.context_length, cfg.vocab_size, _targets_mask(cfg))
 
     def set_logit_scale(self, logit_scale_exp: float):
         self._check(self.lib.ttl_set_logit_scale(self._h, float(logit_scale_exp)))

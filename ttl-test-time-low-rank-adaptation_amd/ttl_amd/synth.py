@@ -114,7 +114,7 @@ def token_ids(n_prompts: int, cfg, seed: int = 0) -> np.ndarray:
     return ids
 
 
-def lora_init(cfg, seed: int = 0, targets=("q_proj", "v_proj"), tower="vision_model") -> dict:
+def lora_init(cfg, seed: int = 0, targets=None, tower="vision_model") -> dict:
     """LoRA A (xavier_normal: std = sqrt(2/(D+r)), clip/custom_clip.py:152-153,184-187) and
     B = 0 (peft default) for every layer, keyed like the reference's parameter names
     (``tower`` = "vision_model" or "text_model")."""
@@ -122,6 +122,9 @@ def lora_init(cfg, seed: int = 0, targets=("q_proj", "v_proj"), tower="vision_mo
     std = np.sqrt(2.0 / (D + r))
     out = {}
     tag = "" if tower == "vision_model" else "t."
+    if targets is None:
+        from .config import ordered_targets
+        targets = ordered_targets(cfg)
     for i in range(cfg.layers):
         for t in targets:
             base = f"{tower}.encoder.layers.{i}.self_attn.{t}."
