@@ -1,16 +1,24 @@
 #!/bin/bash
-# Round evidence: bench line + rocprofv3 kernel stats of the same command (default = 2 episodes in flight, and
-# --streams 1), written under gpurun_out/ (copy what should be judged into profiles/).
-R=${1:-r01}
+# Round evidence: bench line + rocprofv3 kernel stats of the same command (default = 3 episodes in flight, and --streams 1),
+# other configurations, view generator; written under gpurun_out/<round>/ (copy what should be judged into profiles/).
+#   bash tools/collect_profiles.sh r02
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/$R
-python3 bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
-python3 bench.py --streams 1 --no-cpu-baseline > gpurun_out/$R/bench_streams1.json 2>> gpurun_out/$R/bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof2 -o p2 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline > gpurun_out/$R/prof2.log 2>&1
-rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --streams 1 --no-cpu-baseline > gpurun_out/$R/prof1.log 2>&1
-python3 bench.py --classes 1000 --no-cpu-baseline > gpurun_out/$R/bench_k1000.json 2>> gpurun_out/$R/bench.err
-python3 bench.py --arch ViT-L/14 --steps 60 --no-cpu-baseline > gpurun_out/$R/bench_l14.json 2>> gpurun_out/$R/bench.err
-python3 bench.py --views 128 --classes 1000 --rank 32 --updates 4 --steps 40 --no-cpu-baseline > gpurun_out/$R/bench_r32_128v_4up.json 2>> gpurun_out/$R/bench.err
-python3 bench.py --precision fp16 --no-cpu-baseline > gpurun_out/$R/bench_fp16.json 2>> gpurun_out/$R/bench.err
-ls -la gpurun_out/$R gpurun_out/$R/prof2 gpurun_out/$R/prof1
+O=gpurun_out/$R; mkdir -p $O
+python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 bench.py --streams 1 --no-cpu-baseline --no-parity --no-fp16-leg > $O/bench_streams1.json 2>> $O/bench.err
+Q="--no-cpu-baseline --no-parity --no-fp16-leg"
+rocprofv3 --kernel-trace --stats -d $O/prof3 -o p3 --output-format csv -- python3 bench.py --steps 60 --warmup 10 $Q > $O/prof3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --streams 1 $Q > $O/prof1.log 2>&1
+python3 bench.py --classes 1000 $Q > $O/bench_k1000.json 2>> $O/bench.err
+python3 bench.py --arch ViT-L/14 --steps 60 $Q > $O/bench_l14.json 2>> $O/bench.err
+python3 bench.py --views 128 --classes 1000 --rank 32 --updates 4 --steps 40 $Q > $O/bench_r32_128v_4up.json 2>> $O/bench.err
+python3 bench.py --views 128 --classes 1000 --rank 32 --updates 16 --steps 20 $Q > $O/bench_r32_128v_16up.json 2>> $O/bench.err
+python3 bench.py --views 8 --classes 10 --graph 1 --steps 400 $Q > $O/bench_8v_graph.json 2>> $O/bench.err
+python3 tools/text_mode_bench.py > $O/text_mode.log 2>&1
+python3 tools/views_bench.py > $O/views.log 2>&1
+python3 -m ttl_amd.eval --gpu_views 1 --images 1500 > $O/eval_gpu_views.log 2>&1
+python3 tools/trace_shapes.py $O/prof1/p1_kernel_trace.csv gemm > $O/prof1_gemm_shapes.txt 2>&1
+ls $O
+tail -c 600 $O/bench.err
