@@ -15,6 +15,14 @@
 //     requested before the epilogue of the current one, so a tile's prologue latency hides under the stores
 //   * tile order: the 8 XCDs own contiguous row-panel ranges; inside an XCD column-major (all row panels of a
 //     256-column weight slice before the next slice: slice + panels fit the 4 MiB L2) or row-major
+//
+// Tried against this kernel and measured slower (kept out of the tree):
+//   * the same 160 x 256 tile as TWO independent 4-wave blocks per CU (each wave 160 x 64, 32-deep K-tiles so that a 3-stage ring
+//     fits 78 KiB per block, conflict-free 64-B-row LDS image): meant to hide one block's epilogue under the other's MFMAs;
+//     QKV 56.9 vs 43.8 us, fc2 89 vs 65 us on cold operands, 3.30 vs 2.82 ms of GEMM per episode in situ — the speed of round 1's
+//     160 x 128 kernel.  Half-line (64 B per row) DMA pieces and twice the barriers per K cost more than the asynchrony buys.
+//   * 224 x 256 and 256 x 256 tiles (two LDS stages only), 160 x 256 with two stages: -12 ... -15 %.
+//   * starting half of the blocks 1-4 us late (de-synchronising the epilogue store bursts): the delay is simply exposed.
 #include <stdlib.h>
 
 #include <atomic>
