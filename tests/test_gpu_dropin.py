@@ -367,3 +367,23 @@ def test_target_modules_k_and_out_on_the_host_surface():
     got = {n.replace("image_encoder.", ""): p.detach().cpu().numpy() for n, p in model.named_parameters() if "lora_" in n}
     frac_bad = np.mean([float((np.abs(got[k[6:]] - g[k]) > 1e-3).mean()) for k in g.files if k.startswith("lora1/")])
     assert frac_bad < 0.2, frac_bad
+
+
+def test_coeff_pooling_branch():
+    """model(x, coeff=c) (clip/custom_clip.py:682-684): normalised image features weighted per view, averaged, then scored —
+    against the same computation done by hand from the model's own image features; gradients flow through it."""
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    with torch.no_grad():
+        model.LoRA_reset()
+        c = torch.linspace(0.2, 1.5, x.shape[0], device=x.device)
+        f = model.image_features_of(x)
+        fh = f / f.norm(dim=-1, keepdim=True)
+        pooled = (fh * c.view(-1, 1)).mean(dim=0, keepdim=True)
+        want = model.logit_scale.exp().to(x.device) * pooled @ model.text_features.t()
+        got = model(x, coeff=c)
+    assert got.shape == (1, want.shape[1])
+    assert max_rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    out = model(x, coeff=c)                      # with grad
+    assert out.requires_grad
+    out.logsumexp(1).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.trainable_lora_parameters())

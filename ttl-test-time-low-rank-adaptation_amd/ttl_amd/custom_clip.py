@@ -585,13 +585,18 @@ class ClipTestTimeTuning(nn.Module):
         return f
 
     def inference(self, image, label=None, coeff=None):
-        if coeff is not None:
-            raise NotImplementedError("coeff pooling (clip/custom_clip.py:682-684) is unused by ttl.py and not built")
         self._ensure_engine()
         params = self.trainable_lora_parameters()
         # grad mode is off inside Function.forward, so decide here whether a graph is wanted
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _VitLogitsFn.apply(self, save, image, *params)
+        logits = _VitLogitsFn.apply(self, save, image, *params)
+        if coeff is not None:
+            # clip/custom_clip.py:682-684: the normalised image features are weighted per view and averaged BEFORE the product
+            # with the text features.  logits are linear in those features (logit_scale * f_hat @ T^T), so the pooled logits are
+            # the coeff-weighted mean of the per-view logits — exact up to fp32 summation order, and differentiable through
+            # the same autograd node.  (Unused by ttl.py; kept for surface completeness.)
+            logits = (logits * coeff.view(-1, 1).to(logits.dtype)).mean(dim=0, keepdim=True)
+        return logits
 
     def forward(self, input, label=None, coeff=None):
         if isinstance(input, tuple) or input.dim() == 2:
