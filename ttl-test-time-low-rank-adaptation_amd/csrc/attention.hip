@@ -14,6 +14,8 @@
 // ds_read_b128 row reads AND for the transposed 4x16 block reads.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace {
@@ -579,8 +581,8 @@ hipError_t set_smem(K kernel, int bytes) {
 template <int NKT, int CH>
 hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
-    static bool done = false;
-    if (!done) { hipError_t e = set_smem(attn_fwd_w_kernel<NKT, CH>, SMEM); if (e != hipSuccess) return e; done = true; }
+    static std::atomic<bool> done{false};
+    if (!done.load()) { hipError_t e = set_smem(attn_fwd_w_kernel<NKT, CH>, SMEM); if (e != hipSuccess) return e; done.store(true); }
     hipLaunchKernelGGL((attn_fwd_w_kernel<NKT, CH>), dim3(n * H), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
@@ -588,8 +590,8 @@ hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n,
 template <int NKT>
 hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
-    static bool done = false;
-    if (!done) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done = true; }
+    static std::atomic<bool> done{false};
+    if (!done.load()) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done.store(true); }
     hipLaunchKernelGGL((attn_fwd_kernel<NKT>), dim3(n * H), dim3(256), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
@@ -609,8 +611,8 @@ hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int
     constexpr int NWK = (TTL_ATTN_NW_DKV == 0) ? NKT : TTL_ATTN_NW_DKV;
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
     constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
-    static bool done = false;
-    if (!done) {
+    static std::atomic<bool> done{false};
+    if (!done.load()) {
         hipError_t e = set_smem(attn_bwd_dq_kernel<NKT, NWQ>, SMEM_A);
         if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true, NWK>, SMEM_B);
         if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false, NWK>, SMEM_B);
@@ -637,8 +639,7 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     if (nkt == 3) return fwd_w<3, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);   // text tower: T = 77
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
-    static int variant = -1;
-    if (variant < 0) { const char* v = getenv("TTL_ATTN_VARIANT"); variant = v ? atoi(v) : 1; }
+    static const int variant = [] { const char* v = getenv("TTL_ATTN_VARIANT"); return v ? atoi(v) : 1; }();
     if (variant >= 1) {
         if (nkt == 7 && variant == 2) return fwd_w<7, 1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
         if (nkt == 7 && variant == 3) return fwd_w<7, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);

@@ -93,9 +93,12 @@ __device__ __forceinline__ int clip8(int v) {
 __global__ __launch_bounds__(256) void views_kernel(const unsigned char* __restrict__ img, int W, const int* __restrict__ boxes,
                                                     const int* __restrict__ table, int kstride, int S, float3 mean, float3 stdv,
                                                     float* __restrict__ out) {
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    const int oy = blockIdx.y, v = blockIdx.z;
-    if (ox >= S) return;
+    // one thread per output pixel of the view, 256 consecutive pixels of the row-major [S][S] plane per block: no idle lanes
+    // whatever S is (one block per output row left 32 of 256 lanes idle at S = 224)
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.z;
+    if (pix >= S * S) return;
+    const int oy = pix / S, ox = pix - oy * S;
     const int flip = boxes[5 * v + 4] & 1;
     const int oxs = flip ? (S - 1 - ox) : ox;   // hflip of the resized crop == mirrored output column
     const int* ty = table + ((size_t)(v * 2 + 0) * S + oy) * kstride;
@@ -135,7 +138,7 @@ int views_kstride(int H, int W, int S) {
 hipError_t launch_make_views(const unsigned char* img, int H, int W, const int* boxes, int n, int S, const float* mean,
                              const float* stdv, float* out, int* table, int kstride, hipStream_t s) {
     hipLaunchKernelGGL(coef_kernel, dim3((S + 255) / 256, 2, n), dim3(256), 0, s, boxes, H, W, S, kstride, table);
-    hipLaunchKernelGGL(views_kernel, dim3((S + 255) / 256, S, n), dim3(256), 0, s, img, W, boxes, table, kstride, S,
+    hipLaunchKernelGGL(views_kernel, dim3((S * S + 255) / 256, 1, n), dim3(256), 0, s, img, W, boxes, table, kstride, S,
                        make_float3(mean[0], mean[1], mean[2]), make_float3(stdv[0], stdv[1], stdv[2]), out);
     return hipGetLastError();
 }
