@@ -125,6 +125,14 @@ int ttl_entropy_select_loss(const float* logits, int n_views, int n_classes, int
 int ttl_tpt_select_loss(const float* logits, int n_views, int n_classes, double rho, int reuse_idx,
                         float* H_out, int64_t* idx_io, int* n_io, float* loss_out,
                         float* dlogits_out, void* stream);
+/* Both entries on the scratch memory of a context (no allocation per call: the step-wise host loop uses these; the
+ * context-free forms above take their scratch from the stream-ordered pool).  N, K <= max(max_views, max_classes). */
+int ttl_ctx_entropy_select_loss(ttl_ctx* ctx, const float* logits, int n_views, int n_classes, int mode, double rho,
+                                float thresh, float margin, float reweight, const unsigned char* keep,
+                                float* H_out, int64_t* idx_out, int* n_out, float* loss_out,
+                                float* dlogits_out, void* stream);
+int ttl_ctx_tpt_select_loss(ttl_ctx* ctx, const float* logits, int n_views, int n_classes, double rho, int reuse_idx,
+                            float* H_out, int64_t* idx_io, int* n_io, float* loss_out, float* dlogits_out, void* stream);
 
 /* loss.backward() restricted to what the reference's graph contains: head ->
  * post-LN -> layers layer_hi..layer_lo, writing dA/dB of q_proj and v_proj into the bound grads

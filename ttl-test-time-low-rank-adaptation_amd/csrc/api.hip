@@ -784,6 +784,28 @@ int ttl_tpt_select_loss(const float* logits, int N, int K, double rho, int reuse
     return 0;
 }
 
+// the same two entries on a context's own scratch (no allocation on the step-wise path; a context serves one stream at a time)
+int ttl_ctx_entropy_select_loss(ttl_ctx* c, const float* logits, int N, int K, int mode, double rho, float thresh, float margin,
+                                float reweight, const unsigned char* keep, float* H_out, int64_t* idx_out, int* n_out, float* loss_out,
+                                float* dlogits_out, void* stream) {
+    if (!c || !logits || !dlogits_out || !n_out) return fail(TTL_EINVAL, "null argument");
+    const int nmax = c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes;
+    if (N < 1 || K < 1 || N > nmax || K > nmax) return fail(TTL_EINVAL, "logits [%d,%d] exceed the context's capacity %d", N, K, nmax);
+    HIP_TRY(launch_entropy_loss(logits, N, K, 0, mode, rho, thresh, margin, reweight, 0, H_out, (long long*)idx_out, n_out, loss_out,
+                                dlogits_out, c->loss_scratch, (hipStream_t)stream, keep));
+    return 0;
+}
+
+int ttl_ctx_tpt_select_loss(ttl_ctx* c, const float* logits, int N, int K, double rho, int reuse_idx, float* H_out, int64_t* idx_io,
+                            int* n_io, float* loss_out, float* dlogits_out, void* stream) {
+    if (!c || !logits || !dlogits_out || !n_io || !idx_io) return fail(TTL_EINVAL, "null argument");
+    const int nmax = c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes;
+    if (N < 1 || K < 1 || N > nmax || K > nmax) return fail(TTL_EINVAL, "logits [%d,%d] exceed the context's capacity %d", N, K, nmax);
+    HIP_TRY(launch_entropy_loss(logits, N, K, 1, TTL_SEL_TOPK, rho, 0.f, 0.f, 0.f, reuse_idx, H_out, (long long*)idx_io, n_io, loss_out,
+                                dlogits_out, c->loss_scratch, (hipStream_t)stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ backward
 static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) {
     if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");

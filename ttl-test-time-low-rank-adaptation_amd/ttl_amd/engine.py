@@ -149,7 +149,7 @@ class TTLEngine:
         th = math.log(1000.0) if thresh is None else thresh
         kp = None if keep is None else keep.to(device=dev, dtype=torch.uint8).contiguous()
         with torch.cuda.device(dev):
-            self._check(self.lib.ttl_entropy_select_loss(_ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
+            self._check(self.lib.ttl_ctx_entropy_select_loss(self._h, _ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
                                                         float(reweight), _ptr(kp), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
                                                         _ptr(out["loss"]), _ptr(out["dlogits"]), _stream()))
         return out
@@ -164,7 +164,7 @@ class TTLEngine:
                    n=n if reuse else torch.zeros(1, dtype=torch.int32, device=dev),
                    loss=torch.zeros(1, device=dev), dlogits=torch.empty_like(z))
         with torch.cuda.device(dev):
-            self._check(self.lib.ttl_tpt_select_loss(_ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
+            self._check(self.lib.ttl_ctx_tpt_select_loss(self._h, _ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
                                                     _ptr(out["idx"]), _ptr(out["n"]), _ptr(out["loss"]),
                                                     _ptr(out["dlogits"]), _stream()))
         return out
