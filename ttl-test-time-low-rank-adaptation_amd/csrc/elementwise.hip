@@ -83,50 +83,70 @@ __global__ void cls_rows_kernel(float* __restrict__ h, const float* __restrict__
 // ---- LayerNorm: one wave per row, D <= 1024, D % 4 == 0.  Lane l owns float4 chunks l, l+64, ...
 constexpr int LN_MAXC = 4;
 
+// RPW rows per wave: all of a wave's row loads are requested before the first reduction (more bytes in flight per wave).
+// Measured in situ (tools/ew_macro_ab.sh TTL_LN_RPW 1 2 4): 0.55 / 0.57 / 0.60 ms of this class per episode — one row per
+// wave (more waves in flight) is the fastest; the kernel runs at 4.4 TB/s of its 58 MB (profiles/r02_hbm_kernels.json).
+#ifndef TTL_LN_RPW
+#define TTL_LN_RPW 1
+#endif
+template <int RPW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long row_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y32, op_t* __restrict__ y16, int ld16,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int D, float eps, const int* __restrict__ rowmap) {
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     int lane = threadIdx.x & 63;
     const int nch = D >> 2;
-    const float* xr = x + (size_t)(rowmap ? rowmap[row] : row) * row_stride;
-    float4 v[LN_MAXC];
-    float s = 0.f;
+    float4 v[RPW][LN_MAXC];
+    float s[RPW];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        int c = lane + 64 * i;
-        if (c < nch) {
-            v[i] = *(const float4*)(xr + 4 * c);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float mu = wave_sum(s) / (float)D;
-    float q = 0.f;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, rows - 1);
+        const float* xr = x + (size_t)(rowmap ? rowmap[row] : row) * row_stride;
+        s[r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        int c = lane + 64 * i;
-        if (c < nch) {
-            float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
-            q += (a * a + b * b) + (cc * cc + d * d);
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int c = lane + 64 * i;
+            if (c < nch) v[r][i] = *(const float4*)(xr + 4 * c);
+            else v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);   // (zero beyond nch)
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        int c = lane + 64 * i;
-        if (c < nch) {
-            float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
-            float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
-            float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
-            if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        float mu = wave_sum(s[r]) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int c = lane + 64 * i;
+            if (c < nch) {
+                float a = v[r][i].x - mu, b = v[r][i].y - mu, cc = v[r][i].z - mu, d = v[r][i].w - mu;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int c = lane + 64 * i;
+            if (c < nch) {
+                float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+                float o0 = (v[r][i].x - mu) * rs * g.x + b.x, o1 = (v[r][i].y - mu) * rs * g.y + b.y;
+                float o2 = (v[r][i].z - mu) * rs * g.z + b.z, o3 = (v[r][i].w - mu) * rs * g.w + b.w;
+                if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
+                if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+            }
         }
     }
 }
@@ -293,8 +313,13 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
                             op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
                             hipStream_t s, const int* rowmap) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, y_f32, y_bf16,
-                       ld_bf16, mean, rstd, rows, D, eps, rowmap);
+    // several rows per wave only where there are rows to spare (big launches); small ones stay one row per wave
+    if (TTL_LN_RPW > 1 && rows >= 4096)
+        hipLaunchKernelGGL((ln_fwd_kernel<TTL_LN_RPW>), dim3((rows + 4 * TTL_LN_RPW - 1) / (4 * TTL_LN_RPW)), dim3(256), 0, s, x, row_stride,
+                           gamma, beta, y_f32, y_bf16, ld_bf16, mean, rstd, rows, D, eps, rowmap);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3((rows + 3) / 4), dim3(256), 0, s, x, row_stride, gamma, beta, y_f32, y_bf16,
+                           ld_bf16, mean, rstd, rows, D, eps, rowmap);
     return hipGetLastError();
 }
 

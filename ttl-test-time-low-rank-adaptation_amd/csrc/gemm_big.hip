@@ -11,6 +11,8 @@
 //   * fragments are double-buffered in registers by 32-deep K half: the LDS reads of one half are issued
 //     between the MFMAs of the other (sched_group_barrier), one barrier per K-tile
 //   * LDS image, swizzle, weight-row permutation and the epilogue are those of gemm.hip (gemm_epilogue.hpp)
+//   * bias / residual folded into the accumulators' initial value (bias through a 1 KiB LDS-DMA piece ahead of the tile's first
+//     K-tile, residual read at the top of the tile): the epilogue issues stores only
 //   * persistent tile loop (grid = min(tiles, resident slots)): the first two K-tiles of the NEXT tile are
 //     requested before the epilogue of the current one, so a tile's prologue latency hides under the stores
 //   * tile order: the 8 XCDs own contiguous row-panel ranges; inside an XCD column-major (all row panels of a
@@ -228,15 +230,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
         if constexpr (NFULL != 0) { if (wave < NFULL) wait_dma<NPW + NST>(); else wait_dma<NPW - 1 + NST>(); }
         else wait_dma<NPW + NST>();
     };
-    // bias of the tile's 4 columns of this lane: fetched by inline asm (invisible to hipcc's wait-count pass, which would
-    // answer an ordinary load beside in-flight LDS-DMA with vmcnt(0)) BEFORE the tile's first DMA, so the counted wait at
-    // the top of the tile covers it
-    f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+    // bias of the tile's 256 columns: ONE LDS-DMA piece (wave 4, which carries one piece fewer than waves 0-3) into the KiB
+    // behind the ring, requested BEFORE the tile's first K-tile, so every counted wait that retires K-tile 0 retires it too;
+    // the lanes read their 4 columns behind the top-of-tile barrier.  (An ordinary load next to in-flight LDS-DMA makes hipcc
+    // wait vmcnt(0); a VGPR-destination inline-asm load is only order-pinned, not allocation-pinned — guide §5.7 item 1.)
+    char* const sbias = smem + STAGES * STAGE;
     auto fetch_bias = [&](int col0) {
-        if (a.bias) {
-            const float* bp = a.bias + col0 + wn * 64 + 4 * li;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(biasv) : "v"(bp) : "memory");
-        }
+        if (a.bias && wave == 4)
+            __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(a.bias + col0) + lane * 16), LDS_PTR(sbias), 16, 0, 0);
     };
 
     f32x4 acc[MT][4];
@@ -288,13 +289,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
                     rsd[mt][r] = *(const f32x4*)(a.resid + (size_t)(row0 + wm * WM + mt * 16 + 4 * lg + r) * a.ldr + col0 + wn * 64 + 4 * li);
         }
         char *cur = s0, *nxt = s1, *nn = s2;
-        // K-tile 0 landed (STAGES == 3: K-tile 1 may still fly), and with it the bias
+        // K-tile 0 landed (STAGES == 3: K-tile 1 may still fly), and with it the bias piece (older than K-tile 0)
         if constexpr (STAGES == 3) { if (first) wait_tiles1(); else wait_tiles1_st(); }
         else { if (first) wait_dma<0>(); else wait_dma<NST>(); }
-        asm volatile("" : "+v"(biasv));
         BARRIER();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAGES == 2) { issue_odd(1, nxt); issue_uni(1, nxt); }
+        f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) biasv = *(const f32x4*)(sbias + (wn * 64 + 4 * li) * 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -416,7 +418,7 @@ int env_int(const char* name, int dflt) {
 template <int MT, int STAGES, int EPI>
 hipError_t launch_big_t(const GemmArgs& a, int order, int max_blocks, hipStream_t s) {
     constexpr int BM = 32 * MT;
-    constexpr int SMEM = STAGES * (BM + BN) * 128;
+    constexpr int SMEM = STAGES * (BM + BN) * 128 + 1024;   // ring + the bias slot
     static std::atomic<uint64_t> done{0};
     hipError_t e = ensure_smem((const void*)gemm_big_kernel<MT, STAGES, EPI>, SMEM, done);
     if (e != hipSuccess) return e;
