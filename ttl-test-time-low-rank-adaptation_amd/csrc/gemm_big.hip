@@ -446,7 +446,9 @@ hipError_t launch_big_v(const GemmArgs& a, int mt, int stages, int order, int ma
 // rows the kernel may store for a launch of M rows with row tiles of 32*mt (unguarded epilogue)
 bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
     if (epi == EPI_PATCH) return false;                       // scattered output rows: guarded kernel of gemm.hip
-    if (epi == EPI_GELU_BWD) return false;                    // its epilogue reads u: 8*MT registers fetched ahead, gemm.hip has them
+    // MLP dgrad: its epilogue reads u (8*MT registers fetched ahead in gemm.hip).  Tried here with u fetched behind the last
+    // barrier: 82 us per launch vs 83-87 us on gemm.hip's kernel (the 77 MB read stays exposed either way) at the price of spills.
+    if (epi == EPI_GELU_BWD) return false;
     if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3) return false;
     if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
     return true;
