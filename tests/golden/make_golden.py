@@ -271,12 +271,42 @@ def run_unit():
     print("unit: wrote", path, f"({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_ties():
+    """Exact entropy ties across the rho*N boundary (bit-identical logit rows): what the reference's torch.argsort
+    (deyo.py:105, ttl.py:46; stable=False) returns for them, so the oracle's and the kernel's tie rule is pinned."""
+    cfg = get_config("tiny")
+    ttl, deyo, cc = H.import_reference(cfg, 0)
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for name, (N, K, rho, dup) in {"t1": (64, 200, 0.1, 3), "t2": (64, 1000, 0.1, 5), "t3": (16, 10, 0.25, 4)}.items():
+        z = torch.randn(N, K, generator=g) * 3.0
+        order = torch.argsort(deyo.softmax_entropy(z))
+        k = int(N * rho)
+        src = int(order[k - 2])                       # rank k-2: the tied group straddles ranks k-2 .. k-3+dup
+        hi = [int(i) for i in order[-(dup - 1):]]     # overwrite the highest-entropy rows (indices on both sides of src)
+        for i in hi:
+            z[i] = z[src]
+        e = deyo.softmax_entropy(z)
+        assert int((e == e[src]).sum()) == dup
+        out[f"{name}/z"] = z.numpy()
+        out[f"{name}/rho"] = np.float64(rho)
+        out[f"{name}/H"] = e.numpy()
+        out[f"{name}/topk/idx"] = torch.argsort(e, descending=False)[:k].numpy().astype(np.int64)     # deyo.py:105
+        out[f"{name}/tpt_idx"] = ttl.select_confident_samples(z, rho)[1].numpy().astype(np.int64)          # ttl.py:43-47
+        out[f"{name}/tied_rows"] = np.array(sorted([src] + hi), np.int64)
+    path = os.path.join(HERE, "unit_ties.npz")
+    np.savez_compressed(path, **out)
+    print("ties: wrote", path, {k: out[k].tolist() for k in out if k.endswith("idx") or k.endswith("rows")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or (["unit"] + list(CASES))
+    which = sys.argv[1:] or (["unit", "ties"] + list(CASES))
     for c in which:
         if c == "unit":
             run_unit()
+        elif c == "ties":
+            run_ties()
         else:
             # one process per case: the reference is patched per geometry at import
             if len(which) > 1:

@@ -170,6 +170,34 @@ def test_entropy_select_loss_vs_reference(lib, unit, s, mode):
     assert max_rel(dz.cpu().numpy(), unit[f"{s}/{mode}/dz"]) < 1e-4
 
 
+@pytest.mark.parametrize("s", ["t1", "t2", "t3"])
+def test_exact_entropy_ties_at_the_selection_boundary(lib, golden_dir, s):
+    """Bit-identical rows straddling rank int(N*rho) (tests/golden/unit_ties.npz, written by the reference's torch.argsort):
+    select_kernel keeps the same SET (the tied group's lowest view indices, ascending; the reference returns that set in an
+    unspecified order) behind the same untied prefix, for the DeYO top-rho mode and the TPT selection."""
+    u = np.load(golden_dir + "/unit_ties.npz")
+    z = torch.from_numpy(u[f"{s}/z"]).cuda()
+    rho = float(u[f"{s}/rho"])
+    N, K = z.shape
+    ref = u[f"{s}/topk/idx"].tolist()
+    tied = sorted(u[f"{s}/tied_rows"].tolist())
+    lead = [i for i in ref if i not in tied]
+    want = lead + tied[:len(ref) - len(lead)]
+    for tpt in (False, True):
+        H = torch.empty(N, device="cuda")
+        idx = torch.full((N,), -1, dtype=torch.int64, device="cuda")
+        n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        dz = torch.empty_like(z)
+        if tpt:
+            chk(lib, lib.ttl_tpt_select_loss(P(z), N, K, rho, 0, P(H), P(idx), P(n), P(loss), P(dz), S()))
+        else:
+            chk(lib, lib.ttl_entropy_select_loss(P(z), N, K, 1, rho, math.log(1000.0), 0.4, 1.0, None, P(H), P(idx), P(n), P(loss), P(dz), S()))
+        torch.cuda.synchronize()
+        assert idx.cpu().numpy()[:int(n.item())].tolist() == want
+        assert sorted(want) == sorted(ref)
+
+
 @pytest.mark.parametrize("s", ["a", "b", "d"])
 def test_tpt_select_loss_vs_reference(lib, unit, s):
     z = torch.from_numpy(unit[f"{s}/z"]).cuda()

@@ -42,6 +42,24 @@ def test_deyo_loss_grad(unit, s, mode):
     assert max_rel(L["dz"], unit[f"{s}/{mode}/dz"]) < 1e-4
 
 
+@pytest.mark.parametrize("s", ["t1", "t2", "t3"])
+def test_exact_entropy_ties_at_the_selection_boundary(golden_dir, s):
+    """Bit-identical logit rows straddling rank int(N*rho): the reference's torch.argsort (unstable) keeps the LOWEST view
+    indices of the tied group but returns them in no particular order; the oracle (stable sort) selects the same SET, and
+    everything ahead of the tied group in the same order.  The loss is a mean over the set, so the order does not matter."""
+    u = np.load(golden_dir + "/unit_ties.npz")
+    z, rho = u[f"{s}/z"], float(u[f"{s}/rho"])
+    H = O.softmax_entropy(z)
+    ref = u[f"{s}/topk/idx"]
+    assert np.array_equal(ref, u[f"{s}/tpt_idx"])
+    idx = O.select_views(H, "topk", z.shape[0], rho)
+    tied = set(u[f"{s}/tied_rows"].tolist())
+    assert sorted(idx.tolist()) == sorted(ref.tolist())
+    lead = [i for i in ref.tolist() if i not in tied]
+    assert idx.tolist()[:len(lead)] == lead
+    assert [i for i in idx.tolist() if i in tied] == sorted(tied)[:len(idx) - len(lead)]      # lowest indices, ascending
+
+
 def test_adamw_three_steps(unit):
     p = unit["adamw/p0"]
     m = np.zeros_like(p)
