@@ -96,6 +96,32 @@ def _attn_ref(qkv, n, T, H, causal=0):
     return q, k, v, p, o, (m + np.log(den))[..., 0]
 
 
+@pytest.mark.parametrize("n,T,H", [(44, 197, 12), (43, 200, 12), (64, 224, 8)])
+def test_attention_fwd_persistent_kernel(lib, n, T, H):
+    """Launches of >= 512 (view, head) problems with 193 <= T <= 224 take attn_fwd_p_kernel (one workgroup per CU walking
+    2-3 problems, next K/V/q prefetched by LDS-DMA behind counted waits): uneven problem counts per workgroup, padded and
+    unpadded last key tile, with and without the log-sum-exp output (different store counts under the counted wait),
+    bitwise repeatable."""
+    D = H * 64
+    g = torch.Generator().manual_seed(n + T)
+    qkv = (torch.randn(n * T, 3 * D, generator=g)).to(torch.bfloat16)
+    qkv[:, :D] *= 1.5
+    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, 0)
+    o_ref = o.transpose(0, 2, 1, 3).reshape(n * T, D)
+    dq = qkv.cuda()
+    outs = []
+    for with_lse in (True, False, True):
+        out = torch.full((n * T, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(n, H, T, device="cuda")
+        chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse) if with_lse else None, n, T, H, 0, S()))
+        torch.cuda.synchronize()
+        assert max_rel(out.float().cpu().numpy(), o_ref) < 6e-3
+        if with_lse:
+            assert np.abs(lse.cpu().numpy() - lse_ref).max() < 2e-4
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("n,T,H,causal", [(2, 17, 2, 0), (3, 197, 2, 0), (1, 257, 4, 0), (2, 50, 12, 0), (1, 150, 1, 0),
                                           (3, 77, 8, 1), (2, 77, 2, 1), (2, 17, 2, 1), (1, 197, 2, 1)])
 def test_attention_fwd_bwd(lib, n, T, H, causal):

@@ -277,6 +277,178 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
     }
 }
 
+// Timing-only ablations of attn_fwd_p_kernel (results wrong on purpose): 1 = no arithmetic, 2 = no prefetch of the next problem
+#ifndef TTL_ATTN_DIAG
+#define TTL_ATTN_DIAG 0
+#endif
+// 16 B per lane, global -> LDS (M0 = wave-uniform LDS base, lane-linear destination), invisible to hipcc's wait-count pass
+__device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
+}
+
+// ------------------------------------------------------------------------------ forward, persistent (vision towers)
+// One workgroup per CU walks (view, head) problems p = blockIdx.x, + gridDim.x, ...; the K/V tiles of problem i+1 are
+// requested by LDS-DMA into the second half of the LDS while problem i is multiplied, so the kernel streams q/k/v at the
+// rate the memory side delivers them instead of alternating a load phase and a compute phase over 1.5 rounds of blocks
+// (attn_fwd_w_kernel: 768 blocks on 512 slots).  NKT waves, wave w owns query rows 32w..32w+31 as above; with one block per CU
+// a wave may use 256 VGPRs, so CH = NKT (whole score row in registers, no online rescale) is affordable for T <= 224.
+// LDS addresses are per-lane constants + immediates (the swizzle of a row depends on its low 4 bits only, tiles start at
+// multiples of 16 rows).  Not causal (the text tower keeps attn_fwd_w_kernel).
+template <int NKT, int CH>
+__global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
+                                                             int ldo, float* __restrict__ lse, int T, int H, int nprob) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32, NTHR = 64 * NKT, TILE = TP * 128, BUF = 2 * TILE, QOFF = 2 * BUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = H * 64;
+    const int h = lane >> 5, l31 = lane & 31;
+    // row-read offsets of the K tile (row l31 of a 32-row block, 16-B chunk 2*ks + h); the q rows of this wave likewise
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + h) ^ swz(l31)) << 4);
+    // transposed-read offsets of the V tile: [dt][lo/hi] (tr_frag with kb = 0, cb = 32*dt)
+    int voff[2][2];
+    {
+        const int grp = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) voff[dt][hh] = TILE + tile_off(8 * hh + 4 * h + qq, 32 * dt + 16 * grp + 4 * pp);
+    }
+    // K/V: this thread's 4 chunks each (chunk c16 = i*NTHR + tid -> row c16 >> 3, slot c16 & 7); q: every wave fetches ITS OWN
+    // 32 rows (4 instructions of 8 rows), so re-filling the q tile needs no barrier, only the wave's own reads retired.
+    // The DMA is issued from inline asm: with the builtin, hipcc's wait-count pass puts vmcnt(0) in front of the first
+    // ds_read_b64_tr_b16 that follows (it cannot tell that the transposed read touches the OTHER half of the LDS), which
+    // would serialise prefetch and PV.  There is no ordinary load in the loop, so the pass has nothing to wait for; the
+    // waits that matter are the explicit counted ones at the top of the problem loop.
+    auto stage = [&](const op_t* qg, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c16 = i * NTHR + tid, r = c16 >> 3, pz = c16 & 7;
+            const int c = pz ^ swz(r);
+            const size_t go = (size_t)min(r, T - 1) * ld + c * 8;
+            dma16_untracked(qg + D + go, buf + (i * NTHR + wave * 64) * 16);
+            dma16_untracked(qg + 2 * D + go, buf + TILE + (i * NTHR + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wave + 8 * i + (lane >> 3), c = (lane & 7) ^ swz(r);
+            dma16_untracked(qg + (size_t)min(r, T - 1) * ld + c * 8, smem + QOFF + (32 * wave + 8 * i) * 128);
+        }
+    };
+    const int q = wave * 32 + l31;
+    int p = blockIdx.x;
+    int img = p / H, head = p - img * H;
+    stage(qkv + (size_t)img * T * ld + head * 64, smem);
+
+    constexpr float C2 = SCALE * 1.4426950408889634f;
+    for (int it = 0;; ++it) {
+        const int boff = (it & 1) * BUF;
+        // q/K/V of this problem landed (12 DMA operations per lane); younger than them are only the previous problem's
+        // output stores (8, + 1 with lse), which may stay in flight
+        if (it == 0) __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
+        else if (lse) __builtin_amdgcn_s_waitcnt((9 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
+        else __builtin_amdgcn_s_waitcnt((8 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        opx8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const opx8*)(smem + QOFF + 32 * wave * 128 + koff[ks]);
+        // next problem: K/V into the other half of the LDS (everyone is past the barrier, so nobody reads that half any
+        // more), q over this wave's own rows once they are in registers
+        const int pn = p + gridDim.x;
+        const bool more = pn < nprob;
+        int imgn = img, headn = head;
+        if (more) {
+            imgn = pn / H; headn = pn - imgn * H;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (TTL_ATTN_DIAG != 2) stage(qkv + (size_t)imgn * T * ld + headn * 64, smem + (boff ^ BUF));
+        }
+        int kb[4], vb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kb[ks] = koff[ks] + boff;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) vb[dt][hh] = voff[dt][hh] + boff;
+
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 o[2] = {};
+#pragma unroll
+        for (int c0 = 0; c0 < (TTL_ATTN_DIAG == 1 ? 0 : NKT); c0 += CH) {
+            f32x16 st[CH];
+            float mx = m_run;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int kt = c0 + j;
+                if (kt < NKT) {
+                    f32x16 a = {};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) a = MFMA32(*(const opx8*)(smem + kb[ks] + 32 * kt * 128), qf[ks], a, 0, 0, 0);
+                    if (kt == NKT - 1 && 32 * NKT > T) {     // only the last key tile holds padded keys
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (32 * kt + acc_row(r, lane) >= T) a[r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, a[r]);
+                    st[j] = a;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mc = mx * C2;
+            float alpha = 1.f;
+            if (CH < NKT) alpha = __builtin_amdgcn_exp2f(m_run * C2 - mc);   // 0 on the first chunk (m_run = -inf)
+            m_run = mx;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (c0 + j < NKT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float e = __builtin_amdgcn_exp2f(fmaf(st[j][r], C2, -mc));
+                        st[j][r] = e;
+                        sum += e;
+                    }
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            l_run = (CH < NKT) ? l_run * alpha + sum : sum;
+            if (CH < NKT && c0 > 0) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (c0 + j < NKT) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const opx8 pf = acc_frag(st[j], s);
+                        const int kbyte = (32 * (c0 + j) + 16 * s) * 128;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + vb[dt][0] + kbyte));
+                            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + vb[dt][1] + kbyte));
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            o[dt] = MFMA32(__builtin_bit_cast(opx8, v), pf, o[dt], 0, 0, 0);
+                        }
+                    }
+                }
+        }
+        if (q < T) {
+            store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / l_run, lane);
+            if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = m_run * SCALE + __logf(l_run);
+        }
+        if (!more) break;
+        p = pn; img = imgn; head = headn;
+    }
+}
+
 // ------------------------------------------------------------------------------ backward: dQ
 template <int NKT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
@@ -587,6 +759,25 @@ hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n,
     return hipGetLastError();
 }
 
+template <int NKT, int CH>
+hipError_t fwd_p(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+    constexpr int SMEM = 5 * NKT * 32 * 128;     // two (K, V) pairs + q
+    static std::atomic<bool> done{false};
+    static std::atomic<int> ncu{0};
+    if (!done.load()) {
+        hipError_t e = set_smem(attn_fwd_p_kernel<NKT, CH>, SMEM);
+        if (e != hipSuccess) return e;
+        int dev = 0; hipDeviceProp_t pr;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&pr, dev)) != hipSuccess) return e;
+        ncu.store(pr.multiProcessorCount);
+        done.store(true);
+    }
+    const int nprob = n * H;
+    const int grid = nprob < ncu.load() ? nprob : ncu.load();
+    hipLaunchKernelGGL((attn_fwd_p_kernel<NKT, CH>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob);
+    return hipGetLastError();
+}
+
 template <int NKT>
 hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
@@ -639,7 +830,10 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     if (nkt == 3) return fwd_w<3, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);   // text tower: T = 77
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
-    static const int variant = [] { const char* v = getenv("TTL_ATTN_VARIANT"); return v ? atoi(v) : 1; }();
+    static const int variant = [] { const char* v = getenv("TTL_ATTN_VARIANT"); return v ? atoi(v) : 4; }();
+    if (variant == 4 && !causal && n * H >= 512) {     // persistent, K/V of the next problem prefetched (big launches only)
+        if (nkt == 7) return fwd_p<7, 7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);     // T = 257: five tiles of 36 KiB do not fit
+    }
     if (variant >= 1) {
         if (nkt == 7 && variant == 2) return fwd_w<7, 1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
         if (nkt == 7 && variant == 3) return fwd_w<7, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
