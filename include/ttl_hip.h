@@ -82,6 +82,11 @@ void ttl_ctx_destroy(ttl_ctx* ctx);
  * layouts and synchronises.  Replaces CLIPModel.from_pretrained(...).to(device),
  * clip/custom_clip.py:581. */
 int ttl_load_weight(ttl_ctx* ctx, const char* name, const float* data, size_t count);
+/* The same for a checkpoint kept in another element type (SURVEY.md §8b `ttl_load_weights(ctx, name, ptr, dtype)`): fp16 and bf16
+ * tensors are widened to fp32 exactly and then take the path above.  Replaces CLIPModel.from_pretrained(..., torch_dtype=...),
+ * clip/custom_clip.py:581. */
+enum { TTL_DTYPE_F32 = 0, TTL_DTYPE_F16 = 1, TTL_DTYPE_BF16 = 2 };
+int ttl_load_weight_typed(ttl_ctx* ctx, const char* name, const void* data, size_t count, int dtype);
 /* 0 once every tensor of the geometry has been loaded, else TTL_ESTATE (message lists one). */
 int ttl_weights_ready(ttl_ctx* ctx);
 
@@ -89,6 +94,10 @@ int ttl_weights_ready(ttl_ctx* ctx);
  * features + logit head inputs of clip/custom_clip.py:651-663,686 (constant per dataset, Q12). */
 int ttl_set_text_features(ttl_ctx* ctx, const float* tfeat, int n_classes, float logit_scale_exp,
                           void* stream);
+/* logits[v][k] = exp(logit_scale) * <f_v / ||f_v||, t̂_k> for image features f [n_views, E] (fp32, device, not normalised)
+ * against the context's cached class embeddings: the logit head of clip/custom_clip.py:679-686 on its own (SURVEY.md §8b
+ * `ttl_head_logits`), e.g. to re-score cached image features after ttl_set_text_features switched the label set. */
+int ttl_head_logits(ttl_ctx* ctx, const float* feats, int n_views, float* logits_out, void* stream);
 
 /* Bind the trainable LoRA parameters and their gradients: two flat fp32 device buffers laid out
  * in the order of the 12 param groups of ttl.py:195-213 — for layer = layer_lo..layer_hi:

@@ -129,6 +129,37 @@ def test_stepwise_api_equals_fused_episode():
     eng.close()
 
 
+def test_half_precision_checkpoints_and_the_logit_head_entry():
+    """SURVEY §8b entries: ttl_load_weight_typed (fp16 / bf16 tensors widened exactly: same logits, bit for bit, as loading the
+    widened fp32 values) and ttl_head_logits (the logit stage on its own == the logits ttl_vit_forward produced from the same
+    features; re-scores cached features after the class set changed)."""
+    g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
+    xt = torch.from_numpy(x)
+    outs = {}
+    for dt in (torch.float16, torch.bfloat16):
+        Wh = {k: (torch.from_numpy(np.asarray(v, np.float32)).to(dt) if isinstance(v, np.ndarray) and v.ndim >= 1 else v) for k, v in W.items()}
+        Ww = {k: (v.float().numpy() if isinstance(v, torch.Tensor) else v) for k, v in Wh.items()}
+        eng_h, _, _ = make_engine(cfg, Wh, lora0, tf, x.shape[0])
+        eng_w, _, _ = make_engine(cfg, Ww, lora0, tf, x.shape[0])
+        lh, fh = eng_h.forward(xt, want_features=True)
+        lw = eng_w.forward(xt)
+        torch.cuda.synchronize()
+        assert torch.equal(lh, lw)
+        assert torch.equal(eng_h.head_logits(fh), lh)
+        outs[dt] = (eng_h, fh)
+    # another class set on cached features (K' = 3 of the K classes, re-normalised rows stay unit norm)
+    eng, fh = outs[torch.float16]
+    eng.set_text_features(torch.from_numpy(tf[:3]), float(np.exp(W["logit_scale"])))
+    z = eng.head_logits(fh).cpu().numpy()
+    f = fh.cpu().numpy().astype(np.float64)
+    ref = np.exp(W["logit_scale"]) * (f / np.linalg.norm(f, axis=1, keepdims=True)) @ tf[:3].astype(np.float64).T
+    assert max_rel(z, ref) < 1e-5
+    from ttl_amd._lib import TtlError
+    with pytest.raises(TtlError):
+        eng.lib.ttl_load_weight_typed  # exported
+        eng._check(eng.lib.ttl_load_weight_typed(eng._h, b"visual_projection.weight", None, 4, 7))
+
+
 def test_errors_are_loud():
     from ttl_amd import _lib
     from ttl_amd.config import get_config

@@ -352,6 +352,38 @@ static int upload(ttl_ctx* c, const float* data, size_t count, float** tmp) {
     return 0;
 }
 
+// IEEE half -> float, exact (subnormals, inf, nan)
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t ex = (h >> 10) & 31u, man = h & 1023u, bits;
+    if (ex == 0) {
+        if (!man) bits = sign;
+        else {
+            int sh = 0;
+            while (!(man & 1024u)) { man <<= 1; ++sh; }
+            bits = sign | ((uint32_t)(113 - sh) << 23) | ((man & 1023u) << 13);
+        }
+    } else if (ex == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((ex + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+int ttl_load_weight_typed(ttl_ctx* c, const char* name, const void* data, size_t count, int dtype) {
+    if (dtype == TTL_DTYPE_F32) return ttl_load_weight(c, name, (const float*)data, count);
+    if (dtype != TTL_DTYPE_F16 && dtype != TTL_DTYPE_BF16) return fail(TTL_EINVAL, "%s: unknown dtype %d", name ? name : "?", dtype);
+    if (!c || !name || !data) return fail(TTL_EINVAL, "null argument");
+    std::vector<uint16_t> raw(count);
+    HIP_TRY(hipMemcpy(raw.data(), data, count * sizeof(uint16_t), hipMemcpyDefault));     // host or device source
+    std::vector<float> wide(count);
+    for (size_t i = 0; i < count; ++i) {
+        if (dtype == TTL_DTYPE_BF16) { const uint32_t b = (uint32_t)raw[i] << 16; memcpy(&wide[i], &b, 4); }
+        else wide[i] = half_bits_to_float(raw[i]);
+    }
+    return ttl_load_weight(c, name, wide.data(), count);
+}
+
 int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t count) {
     if (!c || !name || !data) return fail(TTL_EINVAL, "null argument");
     const size_t D = c->D, F = c->F, E = c->E, T = c->T;
@@ -738,6 +770,17 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     }
     c->saved = save != 0;
     c->saved_n = n;
+    return 0;
+}
+
+int ttl_head_logits(ttl_ctx* c, const float* feats, int n, float* logits_out, void* stream) {
+    if (!c || !feats || !logits_out) return fail(TTL_EINVAL, "null argument");
+    if (c->text) return fail(TTL_ESTATE, "ttl_head_logits on a text-tower context");
+    if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
+    if (c->K < 1) return fail(TTL_ESTATE, "ttl_set_text_features first");
+    HeadArgs a = head_args(c, nullptr, nullptr, logits_out);
+    a.f = const_cast<float*>(feats);      // read only by the logit stage
+    HIP_TRY(launch_head_logits(a, n, (hipStream_t)stream));
     return 0;
 }
 

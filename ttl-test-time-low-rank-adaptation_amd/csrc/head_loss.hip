@@ -367,6 +367,11 @@ hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_head_logits(const HeadArgs& a, int n, hipStream_t s) {
+    hipLaunchKernelGGL(head_logits_kernel, dim3((a.K + HO - 1) / HO, n), dim3(HB), a.E * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, op_t* dh16, int n, hipStream_t s) {
     hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HO - 1) / HO, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
     hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HO - 1) / HO, n), dim3(HB), a.E * sizeof(float), s, a);

@@ -114,6 +114,8 @@ struct HeadArgs {
     float* tmp_e; float* tmp_d;  // scratch [n,E], [n,D] (backward)
 };
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s);
+// only the logit stage: a.f [n,E] (not normalised) x a.tfeatT -> a.logits [n,K]
+hipError_t launch_head_logits(const HeadArgs& a, int n, hipStream_t s);
 // dlogits [n,K] -> gradient of the CLS rows, compact [n,D] fp32 + bf16 copy (all other rows of
 // the stream gradient are zero)
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls, op_t* dcls_bf16, int n, hipStream_t s);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ttl_ctx_create": (_I, [C.POINTER(ttl_config), C.POINTER(_P)]),
     "ttl_ctx_destroy": (None, [_P]),
     "ttl_load_weight": (_I, [_P, C.c_char_p, _P, _Z]),
+    "ttl_load_weight_typed": (_I, [_P, C.c_char_p, _P, _Z, _I]),
+    "ttl_head_logits": (_I, [_P, _P, _I, _P, _P]),
     "ttl_weights_ready": (_I, [_P]),
     "ttl_set_text_features": (_I, [_P, _P, _I, _F, _P]),
     "ttl_bind_lora": (_I, [_P, _P, _P, _Z]),

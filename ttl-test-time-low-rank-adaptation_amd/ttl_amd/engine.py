@@ -88,6 +88,13 @@ class TTLEngine:
             for name, a in state.items():
                 if name == "logit_scale":
                     continue
+                if isinstance(a, torch.Tensor) and a.dtype in (torch.float16, torch.bfloat16):
+                    a = a.detach().contiguous()            # half-precision checkpoints: widened exactly inside the library
+                    if a.is_cuda and a.device != self.device:
+                        a = a.to(self.device)
+                    self._check(self.lib.ttl_load_weight_typed(self._h, name.encode(), C.c_void_p(a.data_ptr()), a.numel(),
+                                                               1 if a.dtype == torch.float16 else 2))
+                    continue
                 if isinstance(a, torch.Tensor):
                     a = a.detach().to(torch.float32).contiguous()
                     if a.is_cuda and a.device != self.device:
@@ -105,6 +112,14 @@ class TTLEngine:
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_set_text_features(self._h, _ptr(t), t.shape[0], float(logit_scale_exp), _stream()))
         self.n_classes = int(t.shape[0])
+
+    def head_logits(self, feats: torch.Tensor) -> torch.Tensor:
+        """exp(logit_scale) * normalize(feats) @ t_hat^T against the cached class embeddings (clip/custom_clip.py:679-686)."""
+        f = feats.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(f.shape[0], self.n_classes, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_head_logits(self._h, _ptr(f), f.shape[0], _ptr(out), _stream()))
+        return out
 
     def bind_lora(self, params_flat: torch.Tensor):
         assert params_flat.numel() == self.n_lora and params_flat.dtype == torch.float32
