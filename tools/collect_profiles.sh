@@ -18,7 +18,7 @@ python3 bench.py --views 128 --classes 1000 --rank 32 --updates 16 --steps 20 $Q
 python3 bench.py --views 8 --classes 10 --graph 1 --steps 400 $Q > $O/bench_8v_graph.json 2>> $O/bench.err
 python3 tools/text_mode_bench.py > $O/text_mode.log 2>&1
 python3 tools/views_bench.py > $O/views.log 2>&1
-python3 -m ttl_amd.eval --gpu_views 1 --images 1500 > $O/eval_gpu_views.log 2>&1
+PYTHONPATH=ttl-test-time-low-rank-adaptation_amd python3 -m ttl_amd.eval --gpu_views 1 --images 1500 > $O/eval_gpu_views.log 2>&1
 python3 tools/trace_shapes.py $O/prof1/p1_kernel_trace.csv gemm > $O/prof1_gemm_shapes.txt 2>&1
 ls $O
 tail -c 600 $O/bench.err

@@ -284,7 +284,12 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
 // 16 B per lane, global -> LDS (M0 = wave-uniform LDS base, lane-linear destination), invisible to hipcc's wait-count pass
 __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) {
     const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
+    // M0 is a reserved register that cannot be named as a clobber: saved and restored around the instruction
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(l)
+                 : "memory");
 }
 
 // ------------------------------------------------------------------------------ forward, persistent (vision towers)
