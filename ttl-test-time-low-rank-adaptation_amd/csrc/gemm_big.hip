@@ -23,7 +23,12 @@
 //     fits 78 KiB per block, conflict-free 64-B-row LDS image): meant to hide one block's epilogue under the other's MFMAs;
 //     QKV 56.9 vs 43.8 us, fc2 89 vs 65 us on cold operands, 3.30 vs 2.82 ms of GEMM per episode in situ — the speed of round 1's
 //     160 x 128 kernel.  Half-line (64 B per row) DMA pieces and twice the barriers per K cost more than the asynchrony buys.
-//   * 224 x 256 and 256 x 256 tiles (two LDS stages only), 160 x 256 with two stages: -12 ... -15 %.
+//   * 224 x 256 and 256 x 256 tiles (two LDS stages only), 160 x 256 with two stages: -12 ... -15 %.  Repeated with a spill-free
+//     256 x 256 variant (one fragment set instead of two, no scratch traffic in the K loop; 128 FLOP per staged byte instead of
+//     98): QKV 52 vs 43 us, fc1 75 vs 62 us on cold operands, GEMM time per episode 2.85 vs 2.77 ms.  With two stages the next
+//     K-tile can only be requested once the barrier has released the stage just read, so the CU's L1 request pipeline drains at
+//     every K-step (12 B/clk staged instead of 17.7 with a third stage keeping requests queued): the ring depth matters more
+//     than the bytes per FLOP, and 160 KiB of LDS hold three stages only up to 160 + 256 rows.
 //   * bf16 outputs accumulated transposed (MFMA(w, x), weight rows permuted so a lane owns 8 consecutive columns of one row):
 //     half as many store instructions (16 B each, 16 rows x 64 B per instruction instead of 4 rows x 128 B): GEMM time per
 //     episode 2.88 vs 2.76 ms in situ, 277 vs 285 images/s — the epilogue is bound by lines touched, not by store instructions;
