@@ -49,6 +49,9 @@ CASES = {
     # BASELINE.json configs[2]'s single-GPU workload: the 1000 ImageNet labels
     "b16_n64_k1000_ent0": ("ViT-B/16", 64, 1000, {}),
     "b16_n64_k1000_ent1": ("ViT-B/16", 64, 1000, {"filter_ent": 1}),
+    # BASELINE.json configs[3]'s geometry (patch 14, T = 257, D = 1024, 16 heads, 24 layers, E = 768; adapters on layers 21-23) at a
+    # view count the CPU reference finishes in seconds
+    "l14_n4_k10": ("ViT-L/14", 4, 10, {}),
     # adapters on all four attention projections (BASELINE.json north_star).  The reference hard-codes q_proj + v_proj in its
     # LoraConfig (clip/custom_clip.py:586): these two cases run the UNMODIFIED reference with the harness's peft stand-in told to
     # wrap k_proj / out_proj too (_ref_harness.TARGET_MODULES_OVERRIDE); the reference's LoRA_AB still (re-)initialises q and v

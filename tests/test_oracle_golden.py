@@ -114,6 +114,12 @@ def test_episode_b16_n8_k10():
     _run_case("b16_n8_k10", check_taps=False)
 
 
+def test_episode_l14_n4_k10():
+    """BASELINE config 4's geometry through the reference itself (ViT-L/14: patch 14, T = 257, D = 1024, 16 heads, 24 layers,
+    adapters on layers 21-23) at 4 views."""
+    _run_case("l14_n4_k10", check_taps=False)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent1"])
 def test_episode_b16_n64(name):
