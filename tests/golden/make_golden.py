@@ -52,6 +52,11 @@ CASES = {
     # BASELINE.json configs[3]'s geometry (patch 14, T = 257, D = 1024, 16 heads, 24 layers, E = 768; adapters on layers 21-23) at a
     # view count the CPU reference finishes in seconds
     "l14_n4_k10": ("ViT-L/14", 4, 10, {}),
+    # the run script's other --arch option (patch 32, T = 50)
+    "b32_n8_k10": ("ViT-B/32", 8, 10, {}),
+    # BASELINE.json configs[4]'s features at a CPU-sized view count: rank 32, --tta_steps 2 (= 4 optimizer updates, Q6), top-rho
+    # selection (int(16 * 0.1) = 1 view) on the full ViT-B/16 geometry
+    "b16_r32_n16_steps2": ("ViT-B/16", 16, 10, {"rank": 32, "tta_steps": 2, "filter_ent": 1}),
     # adapters on all four attention projections (BASELINE.json north_star).  The reference hard-codes q_proj + v_proj in its
     # LoraConfig (clip/custom_clip.py:586): these two cases run the UNMODIFIED reference with the harness's peft stand-in told to
     # wrap k_proj / out_proj too (_ref_harness.TARGET_MODULES_OVERRIDE); the reference's LoRA_AB still (re-)initialises q and v

@@ -179,14 +179,16 @@ def test_errors_are_loud():
 
 # ------------------------------------------------------------------ full-size geometries
 @pytest.mark.parametrize("name", ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1",
-                                  "l14_n4_k10"])
+                                  "l14_n4_k10", "b32_n8_k10"])
 def test_vit_b16_against_reference_goldens(name):
     """BASELINE configs 1-3 shapes (ViT-B/16, r=16; 8 views/K=10, 64 views/K=200 and 64 views/K=1000) and config 4's geometry
-    (ViT-L/14, layers 21-23, 4 views) vs the outputs of the reference itself.  bf16 MFMA operands cost 3-5e-3 of the logit range on this model
+    (ViT-L/14, layers 21-23, 4 views) and ViT-B/32 vs the outputs of the reference itself.  bf16 MFMA operands cost 3-5e-3 of the logit range on this model
     (the bf16-emulating oracle sits at the same distance: tests/diag_path.py), the selection set
     is still exactly the reference's."""
     g, cfg, W, x, lora0, tf = load_case(name)
     kw = episode_kwargs(g)
+    # max|logit| of the synthetic ViT-B/32 model is 2.5 (ViT-B/16 fixtures: 5.7-8.9) at the same absolute bf16 error: twice the relative one
+    ts = 2.0 if name.startswith("b32") else 1.0
     eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0])
     snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
     l1, l0 = eng.episode(torch.from_numpy(x).cuda(), snap, m, v, n_updates=kw["n_updates"], objective=kw["objective"],
@@ -194,7 +196,7 @@ def test_vit_b16_against_reference_goldens(name):
                          want_logits0=True)
     torch.cuda.synchronize()
     z0 = l0.cpu().numpy()
-    assert max_rel(z0, g["logits0"]) < 8e-3
+    assert max_rel(z0, g["logits0"]) < 8e-3 * ts
     H = O.softmax_entropy(z0)
     np.testing.assert_allclose(H, g["H"], rtol=0, atol=2.5e-2)
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
@@ -209,12 +211,42 @@ def test_vit_b16_against_reference_goldens(name):
             assert not grads[k].any(), k
             assert np.abs(lora1[k] - g["lora1/" + k]).max() < 1e-7, k     # A' = A(1 - lr*wd) exactly (Q11)
         else:
-            assert max_rel(grads[k], gref) < 1.5e-2, (k, max_rel(grads[k], gref))
+            assert max_rel(grads[k], gref) < 1.5e-2 * ts, (k, max_rel(grads[k], gref))
             dg = np.abs(grads[k] - gref).max() * 1.001
             check_lora_step(lora1[k], g["lora1/" + k], gref, kw["lr"], 1e-3, k, dg=dg)
             assert (np.abs(lora1[k] - g["lora1/" + k]) > 1e-4).mean() < 0.02, k  # >98% of B' within 1e-4
-    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 8e-3
+    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 8e-3 * ts
     assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_r32_four_updates_against_the_reference(precision):
+    """BASELINE config 5's features through the reference itself (fixture b16_r32_n16_steps2: rank 32, --tta_steps 2 = 4 optimizer
+    updates, top-rho selection of 1 of 16 views, full ViT-B/16): first-forward logits and the selection exactly as for one
+    update; after four sign-like AdamW updates (Q11) the adapted prediction agrees to the operand precision and nearly every
+    adapter element sits where the reference's does."""
+    g, cfg, W, x, lora0, tf = load_case("b16_r32_n16_steps2")
+    kw = episode_kwargs(g)
+    assert kw["n_updates"] == 4 and cfg.rank == 32
+    eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision=precision)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    l1, l0 = eng.episode(torch.from_numpy(x).cuda(), snap, m, v, n_updates=4, objective=kw["objective"],
+                         mode=1 if kw["mode"] == "topk" else 0, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"], want_logits0=True)
+    torch.cuda.synchronize()
+    tol = 8e-3 if precision == "bf16" else 1e-3
+    assert max_rel(l0.cpu().numpy(), g["logits0"]) < tol
+    hip_idx, _ = eng.last_selection(x.shape[0])
+    assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1)))
+    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 3 * tol
+    assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
+    lora1 = split(flat, lora0, names)
+    lr = kw["lr"]
+    for k in names:
+        err = np.abs(lora1[k].astype(np.float64) - g["lora1/" + k])
+        assert err.max() <= 2 * lr * 4 + 1e-6, (k, float(err.max()))
+        if np.abs(g["grad/" + k]).max() > 0:
+            assert (err > 0.1 * lr).mean() < (0.05 if precision == "bf16" else 0.02), (k, float((err > 0.1 * lr).mean()))
     eng.close()
 
 
@@ -342,7 +374,7 @@ def test_r32_128_views_multi_step_invariants():
 
 # ------------------------------------------------------------------ fp16-operand build (the reference's autocast dtype)
 @pytest.mark.parametrize("name", ["tiny_deyo", "tiny197_deyo", "b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1",
-                                  "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "l14_n4_k10"])
+                                  "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "l14_n4_k10", "b32_n8_k10"])
 def test_fp16_operands_meet_the_1e3_tolerance(name):
     """libttl_hip_fp16.so: same kernels with IEEE-half MFMA operands (what torch.cuda.amp.autocast() uses in
     the reference's GPU path, ttl.py:79) and a fixed 2^10 loss scale in the backward (cf. GradScaler,

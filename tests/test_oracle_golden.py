@@ -96,9 +96,14 @@ def _run_case(name, check_taps):
             assert ok, (k, max_rel(got, g[k]))
     for k in g.files:
         if k.startswith("lora1/"):
-            gr = g["grad/" + k[6:]] if n_up == 1 else None
-            check_lora_step(out["lora"][k[6:]], g[k], gr, float(g["lr"]),
-                            1e-4 if n_up == 1 else 2e-2, k)
+            if n_up == 1:
+                check_lora_step(out["lora"][k[6:]], g[k], g["grad/" + k[6:]], float(g["lr"]), 1e-4, k)
+            else:
+                # several sign-like updates: an element whose gradient sits at fp32 noise level in one of them lands one
+                # +-lr step away (Q11); all but a handful of elements agree, none is further than the updates allow
+                err = np.abs(np.asarray(out["lora"][k[6:]], np.float64) - g[k])
+                assert (err > 2e-2 * np.abs(g[k]).max()).mean() < 1e-3, (k, float((err > 2e-2 * np.abs(g[k]).max()).mean()))
+                assert err.max() <= 2 * float(g["lr"]) * n_up, (k, float(err.max()))
     assert max_rel(trace[-1]["logits"], g["logits_last"]) < (2e-5 if n_up == 1 else 2e-3)
     assert max_rel(out["logits1"], g["logits1"]) < (1e-4 if n_up == 1 else 2e-3)
     assert np.array_equal(np.argsort(-out["logits1"], 1)[:, :1], g["top5"][:, :1])
@@ -118,6 +123,17 @@ def test_episode_l14_n4_k10():
     """BASELINE config 4's geometry through the reference itself (ViT-L/14: patch 14, T = 257, D = 1024, 16 heads, 24 layers,
     adapters on layers 21-23) at 4 views."""
     _run_case("l14_n4_k10", check_taps=False)
+
+
+def test_episode_b32_n8_k10():
+    """The run script's other --arch option (ViT-B/32: patch 32, T = 50) through the reference itself."""
+    _run_case("b32_n8_k10", check_taps=False)
+
+
+def test_episode_b16_r32_n16_steps2():
+    """BASELINE config 5's features at a CPU-sized view count, through the reference itself: rank 32, --tta_steps 2 = 4 optimizer
+    updates (Q6), top-rho selection (1 of 16 views), full ViT-B/16 geometry."""
+    _run_case("b16_r32_n16_steps2", check_taps=False)
 
 
 @pytest.mark.slow
