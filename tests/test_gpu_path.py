@@ -467,6 +467,30 @@ def test_episode_as_hip_graph_replays_bit_identically():
     assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
 
 
+def test_three_episodes_in_flight_are_bitwise_repeatable():
+    """The bench's regime (ttl_amd.driver.EpisodePipeline, three HIP streams, full ViT-B/16 at 64 views: persistent GEMM and
+    attention blocks of different episodes share the CUs): 18 episodes over two view batches give, for each batch, one and the
+    same adapted prediction bit for bit, equal to the one a single engine computes alone."""
+    from ttl_amd.driver import EpisodePipeline
+    g, cfg, W, x, lora0, tf = load_case("b16_n64_k200_ent0")
+    x0 = torch.from_numpy(x).cuda()
+    x1 = (torch.roll(x0, 3, dims=0) * 0.95).contiguous()
+    eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0])
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    ref = [eng.episode(xx, snap, m, v, n_updates=1).clone() for xx in (x0, x1)]
+    torch.cuda.synchronize()
+    eng.close()
+    pipe = EpisodePipeline(cfg, W, names, lora0, torch.from_numpy(tf), float(np.exp(W["logit_scale"])), "cuda:0",
+                           n_streams=3, max_views=x.shape[0])
+    order = [0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1]
+    outs = [pipe.submit((x0, x1)[j], n_updates=1) for j in order]
+    pipe.synchronize()
+    for j, o in zip(order, outs):
+        assert torch.equal(o, ref[j]), j
+    assert not torch.equal(ref[0], ref[1])
+    pipe.close()
+
+
 def test_empty_selection_leaves_the_adapters_untouched():
     """8 views with --filter_ent 1: int(8 * 0.1) == 0 views survive, the reference returns before backward / step
     (deyo.py:110-113).  The fused episode must do the same: LoRA == snapshot, Adam state zero, logits1 == the
