@@ -299,7 +299,8 @@ __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) 
 // (attn_fwd_w_kernel: 768 blocks on 512 slots).  NKT waves, wave w owns query rows 32w..32w+31 as above; with one block per CU
 // a wave may use 256 VGPRs, so CH = NKT (whole score row in registers, no online rescale) is affordable for T <= 224.
 // LDS addresses are per-lane constants + immediates (the swizzle of a row depends on its low 4 bits only, tiles start at
-// multiples of 16 rows).  Not causal (the text tower keeps attn_fwd_w_kernel).
+// multiples of 16 rows).  Not causal (the text tower keeps attn_fwd_w_kernel).  Chunked (online) softmax in this kernel, 2 / 3 / 4
+// key tiles per chunk: 0.380 / 0.321 / 0.329 ms of attention forward per episode against 0.311 with the whole row (CH = NKT).
 template <int NKT, int CH>
 __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
                                                              int ldo, float* __restrict__ lse, int T, int H, int nprob) {
