@@ -302,7 +302,8 @@ __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) 
 // multiples of 16 rows).  Not causal (the text tower keeps attn_fwd_w_kernel).  Chunked (online) softmax in this kernel, 2 / 3 / 4
 // key tiles per chunk: 0.380 / 0.321 / 0.329 ms of attention forward per episode against 0.311 with the whole row (CH = NKT).
 // Holding the upper waves (w + 4, the SIMD partners of w) back by 0.5-1.8 k cycles so that one wave's softmax runs beside the other's
-// matrix phases: no change (0.308-0.312): what is left is the rate the q/k/v segments arrive at.
+// matrix phases: no change (0.308-0.312): what is left is the rate the q/k/v segments arrive at.  Giving the workgroups of XCD x
+// the views whose q/k/v rows XCD x's tiles of the QKV GEMM have just written (producer / consumer on the same L2): no change either.
 template <int NKT, int CH>
 __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
                                                              int ldo, float* __restrict__ lse, int T, int H, int nprob) {
