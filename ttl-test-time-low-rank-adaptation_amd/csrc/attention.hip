@@ -2,7 +2,9 @@
 //   forward : o = softmax(q k^T / 8) v, row logsumexp saved            (HF modeling_clip.py:259-277)
 //   backward: dq, dk, dv with P recomputed from the saved logsumexp     (autograd of the same)
 //
-// One workgroup (4 waves) per (view, head); the whole K/V (or Q/dO) of the head lives in LDS.
+// One workgroup per (view, head) — one wave per 32-row block of the sequence (attn_fwd_w_kernel, the backward kernels), 4 waves for
+// short sequences — or, for the 64-view forward launches, one persistent workgroup per CU walking (view, head) problems with the
+// next problem's tiles prefetched (attn_fwd_p_kernel); the whole K/V (or Q/dO) of the head lives in LDS.
 // MFMA 32x32x16 bf16 everywhere.  Orientation is chosen so that NO accumulator ever crosses
 // lanes or LDS (guide §3 "accumulator tile as the next MFMA's operand"):
 //   forward / dQ pass : S^T = K Q^T (query on the lane) -> softmax is lane-local ->
