@@ -29,6 +29,10 @@
 //     K-tile can only be requested once the barrier has released the stage just read, so the CU's L1 request pipeline drains at
 //     every K-step (12 B/clk staged instead of 17.7 with a third stage keeping requests queued): the ring depth matters more
 //     than the bytes per FLOP, and 160 KiB of LDS hold three stages only up to 160 + 256 rows.
+//   * a 256 x 256 tile whose third stage lives in REGISTERS (K-tile s+2 requested with ordinary global loads, 32 VGPRs per lane,
+//     written into the LDS stage just read behind the step's barrier; one flat (tile, K-tile) pipeline, 220 VGPRs, no spills):
+//     QKV 57-59 us (160 x 256 ring: 43), dO 30 vs 19 us: the VGPR -> LDS hop (8 ds_write_b128 per lane and K-step beside the
+//     fragment reads) costs more than the extra stage and the 30 % fewer staged bytes buy.
 //   * bf16 outputs accumulated transposed (MFMA(w, x), weight rows permuted so a lane owns 8 consecutive columns of one row):
 //     half as many store instructions (16 B each, 16 rows x 64 B per instruction instead of 4 rows x 128 B): GEMM time per
 //     episode 2.88 vs 2.76 ms in situ, 277 vs 285 images/s — the epilogue is bound by lines touched, not by store instructions;
