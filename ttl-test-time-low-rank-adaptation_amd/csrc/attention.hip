@@ -357,11 +357,10 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
     constexpr float C2 = SCALE * 1.4426950408889634f;
     for (int it = 0;; ++it) {
         const int boff = (it & 1) * BUF;
-        // q/K/V of this problem landed (12 DMA operations per lane); younger than them are only the previous problem's
-        // output stores (8, + 1 with lse), which may stay in flight
+        // q/K/V of this problem landed: the first problem's requests are waited for here, every later problem's at the end of
+        // the previous iteration, AHEAD of that iteration's output stores (vmcnt(0) there retires the 12 DMA operations per lane
+        // without assuming how many store instructions the compiler emits; the stores then stay in flight across the barrier)
         if (it == 0) __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
-        else if (lse) __builtin_amdgcn_s_waitcnt((9 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
-        else __builtin_amdgcn_s_waitcnt((8 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         opx8 qf[4];
@@ -451,6 +450,9 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
                     }
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));     // next problem's q/K/V landed (see the loop top)
+        __builtin_amdgcn_sched_barrier(0);
         if (q < T) {
             store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / l_run, lane);
             if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = m_run * SCALE + __logf(l_run);
