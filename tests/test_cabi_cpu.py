@@ -63,3 +63,42 @@ def test_product_path_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_struct_layouts_match_the_header_and_the_documented_stub(tmp_path):
+    """ttl_config / ttl_episode_args as ctypes sees them (ttl_amd/_lib.py) == as a C compiler lays out include/ttl_hip.h
+    (sizeof + every offsetof), and the ctypes stub printed in INTEGRATION.md lists the same ttl_config fields in the same
+    order (a field missing there shifts nothing visibly but makes the library read past the caller's struct)."""
+    import re
+    import shutil
+    import subprocess
+    import ctypes as C
+    from ttl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ttl_hip.h")).read()
+
+    def c_fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [re.search(r"(\w+)\s*$", part.strip()).group(1) for d in body.split(";") if d.strip() for part in d.split(",")]
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    for name, ct in (("ttl_config", _lib.ttl_config), ("ttl_episode_args", _lib.ttl_episode_args)):
+        fields = c_fields(name)
+        assert fields == [f[0] for f in ct._fields_], (name, fields)
+        src = tmp_path / (name + ".c")
+        prints = "".join('printf("%%zu ", offsetof(%s, %s));' % (name, f) for f in fields)
+        src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ttl_hip.h"\nint main(void){printf("%%zu ", sizeof(%s));%s return 0;}\n'
+                       % (name, prints))
+        exe = tmp_path / name
+        subprocess.check_call([gcc, "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+        nums = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+        assert nums[0] == C.sizeof(ct), (name, nums[0], C.sizeof(ct))
+        assert nums[1:] == [getattr(ct, f).offset for f in fields], name
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class ttl_config(C.Structure):"):doc.index("cfg = ttl_config(")]
+    assert re.findall(r'"(\w+)"', stub) == c_fields("ttl_config")
+    n_init = len(re.search(r"cfg = ttl_config\((.*?)\)", doc).group(1).split(","))
+    assert n_init == len(c_fields("ttl_config"))
+
