@@ -75,6 +75,13 @@ size_t ttl_workspace_bytes(const ttl_config* cfg);
 /* Replaces model construction + .cuda(): clip/custom_clip.py:570-623, ttl.py:178-179. */
 int ttl_ctx_create(const ttl_config* cfg, ttl_ctx** out);
 void ttl_ctx_destroy(ttl_ctx* ctx);
+/* A further context on the SAME model object: the reference has one `model` per process (ttl.py:178-179) that every test
+ * image runs through; here several episodes are in flight per GPU, each in a context of its own (activation arena, LoRA
+ * images), and the frozen weight images — everything but the projection images of the layers that carry adapters, whose
+ * LoRA K-extension columns each context refreshes from its own adapters — are the parent's, read-only.  `parent` must own its
+ * weights (not itself shared), have them all loaded (ttl_weights_ready), have the same model configuration as `cfg`
+ * (max_views / max_classes may differ) and outlive `*out`.  ttl_load_weight on the new context is an error. */
+int ttl_ctx_create_shared(const ttl_config* cfg, ttl_ctx* parent, ttl_ctx** out);
 
 /* Load one fp32 tensor of the HF vision tower by its state-dict name,
  * e.g. "vision_model.encoder.layers.3.mlp.fc1.weight", "visual_projection.weight".

@@ -612,3 +612,79 @@ def test_k_and_out_proj_adapters_vs_oracle(arch, rank, targets):
             assert np.abs(lora1[k] - exp).max() < 2e-8 + 1e-6 * np.abs(exp).max(), k
         assert max_rel(l1.cpu().numpy(), o32["logits1"]) < 3 * ltol, precision
         eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("targets", [None, ("q_proj", "k_proj", "v_proj", "out_proj")])
+def test_head_major_qkv_changes_addresses_only(monkeypatch, precision, targets):
+    """The big-M QKV GEMM writes q/k/v head-major ([view][q|k|v][head][T][64]: contiguous tiles for the attention kernels, HF
+    modeling_clip.py:259-277 computes per head as well) where the small-M path and TTL_QKV_HEAD_MAJOR=0 keep [tokens][3D] rows.
+    Same values through the same arithmetic: logits, gradients, updated weights and the saved q/k/v (as ttl_debug_copy hands
+    them out, row-major) must be BITWISE equal between the two layouts — forward, dense backward (dQ, dK/dV), the rank-1
+    top-layer backward, a k_proj adapter's dK in the first trained layer, and the resumed 1-view inference on the small-M path."""
+    g, cfg, W, x, lora0, tf = load_case("b16_n8_k10")
+    if targets:
+        cfg = cfg.replace(lora_targets=targets)
+        from ttl_amd import synth
+        lora0 = synth.lora_init(cfg, 0)
+        rng = np.random.default_rng(5)
+        for k in lora0:
+            if "lora_B" in k:
+                lora0[k] = (rng.standard_normal(lora0[k].shape) * 0.02).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for hm in ("0", "1"):
+        monkeypatch.setenv("TTL_QKV_HEAD_MAJOR", hm)           # read when the context is created
+        eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision=precision)
+        snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+        z = eng.forward(xd, save=True).clone()
+        M = x.shape[0] * cfg.tokens
+        qkv = [eng.debug_copy("qkv", i, (M, 3 * cfg.width), np.uint16).copy() for i in range(cfg.layer_lo, cfg.layer_hi)]
+        l1, l0 = eng.episode(xd, snap, m, v, n_updates=2, want_logits0=True)
+        torch.cuda.synchronize()
+        res[hm] = (z.cpu().numpy(), qkv, l0.cpu().numpy(), l1.cpu().numpy(), eng.grads.cpu().numpy().copy(), flat.cpu().numpy().copy())
+        eng.close()
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for qa, qb in zip(a[1], b[1]):
+        assert np.array_equal(qa, qb)
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert np.abs(a[4]).max() > 0
+
+
+def test_shared_weight_images_give_the_same_bits():
+    """ttl_ctx_create_shared: a second context on the SAME frozen weight images (one model per process in the reference,
+    ttl.py:178-179) computes bit for bit what a context with private copies computes — with both contexts alive and
+    used alternately, a k_proj / out_proj adapter set so that the private projection images differ between them, and
+    loading into the shared context refused."""
+    from ttl_amd.engine import TTLEngine
+    from ttl_amd import _lib
+    g, cfg, W, x, lora0, tf = load_case("b16_n8_k10")
+    cfg = cfg.replace(lora_targets=("q_proj", "k_proj", "v_proj", "out_proj"))
+    from ttl_amd import synth
+    lora0 = synth.lora_init(cfg, 0)
+    rng = np.random.default_rng(7)
+    loraB = {k: ((rng.standard_normal(v.shape) * 0.02).astype(np.float32) if "lora_B" in k else v) for k, v in lora0.items()}
+    own, flat_o, names = make_engine(cfg, W, lora0, tf, x.shape[0])
+    priv, flat_p, _ = make_engine(cfg, W, loraB, tf, x.shape[0])
+    sh = TTLEngine(cfg, max_views=x.shape[0], max_classes=tf.shape[0], device="cuda:0", share_from=own)
+    with pytest.raises(_lib.TtlError, match="shares its parent"):
+        sh.load_weights({"visual_projection.weight": W["visual_projection.weight"]})
+    sh.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
+    flat_s = torch.cat([torch.from_numpy(loraB[k]).reshape(-1) for k in names]).cuda().contiguous()
+    sh.bind_lora(flat_s)
+    xd = torch.from_numpy(x).cuda()
+    outs = {}
+    for rep in range(2):                       # alternate: the owner's adapters (B = 0) must not leak into the sharer's images
+        for tag, eng, flat in (("own", own, flat_o), ("shared", sh, flat_s), ("private", priv, flat_p)):
+            snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+            l1, l0 = eng.episode(xd, snap, m, v, n_updates=2, want_logits0=True)
+            torch.cuda.synchronize()
+            cur = (l0.cpu().numpy(), l1.cpu().numpy(), eng.grads.cpu().numpy().copy(), flat.cpu().numpy().copy())
+            flat.copy_(snap)
+            if rep:
+                assert all(np.array_equal(p, q) for p, q in zip(outs[tag], cur)), tag
+            outs[tag] = cur
+    assert all(np.array_equal(p, q) for p, q in zip(outs["shared"], outs["private"]))
+    assert not np.array_equal(outs["own"][0], outs["shared"][0])
+    sh.close(); priv.close(); own.close()

@@ -65,6 +65,7 @@ struct Layer {
     float* h_in; float* h_mid;
     op_t* x1ext; op_t* qkv; op_t* attn; op_t* u;
     float* lse; float *mu1, *rs1, *mu2, *rs2;
+    bool qkv_hm;      // layout of `qkv` as the last forward wrote it: head-major [n][3][H][T][64] (big-M QKV GEMM) or row-major [n*T][3D]
     bool trained;     // i >= layer_lo: activations saved, dgrad images kept, gradient flows through it
     bool lora;        // layer_lo <= i <= layer_hi: carries trainable adapters (--layer_range); layers above layer_hi are
                       // frozen in the reference (B == 0 forever, Q10) but still lie on the gradient's path
@@ -80,6 +81,8 @@ struct ttl_ctx {
     // ext = K-extension columns of the QKV GEMMs (nqkv*r rounded up to 64), ldh = pitch of the bf16 stream-gradient buffers
     int tg, ntg, nqkv, sq, sk, sv, has_o, ext, ldh;
     int Mmax;
+    const ttl_ctx* parent = nullptr;        // != null: frozen weight images are the parent's (ttl_ctx_create_shared); read-only here
+    int use_hm = 0; unsigned hm_magic = 0;   // head-major q/k/v from the big-M QKV GEMM (TTL_QKV_HEAD_MAJOR=0: row-major everywhere)
     float scaling;
     std::vector<void*> allocs;
     size_t bytes = 0;
@@ -203,6 +206,19 @@ struct Prof {
     }
 };
 
+// Will the QKV projection `a` (EPI_OP, N = 3D) run on the big-M kernel?  Then its epilogue writes q/k/v head-major
+// (contiguous [T][64] tiles per (view, plane, head)): the attention kernels read whole lines from adjacent addresses instead of
+// 128-B segments at a stride of 3D elements.  Same values, same arithmetic: only the addresses differ.
+bool qkv_goes_head_major(ttl_ctx* c, GemmArgs& a) {
+    if (!c->use_hm || a.N != 3 * c->D) return false;
+    GemmArgs p = a;
+    p.padded = (a.M > c->c.max_views) ? c->Mmax : 0;
+    p.hm_T = c->T; p.hm_magic = c->hm_magic;
+    if (!gemm_takes_big(EPI_OP, p)) return false;
+    a.hm_T = c->T; a.hm_magic = c->hm_magic;
+    return true;
+}
+
 int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     const bool big = a0.M >= 1024;   // launch_gemm's own split: the 160x128 kernel vs the latency-bound small-M path
     Prof p(c, big ? 0 : 6, s);
@@ -253,18 +269,39 @@ size_t ttl_workspace_bytes(const ttl_config* k) {
     return w + act;
 }
 
-int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
+// The weight-side configuration two contexts must agree on to share frozen images (capacities may differ)
+static bool same_model(const ttl_config& a, const ttl_config& b) {
+    return a.image_size == b.image_size && a.patch_size == b.patch_size && a.width == b.width && a.heads == b.heads && a.mlp == b.mlp &&
+           a.layers == b.layers && a.embed == b.embed && a.rank == b.rank && a.layer_lo == b.layer_lo && a.layer_hi == b.layer_hi &&
+           a.tower == b.tower && a.context_length == b.context_length && a.vocab_size == b.vocab_size &&
+           (a.lora_targets ? a.lora_targets : (TTL_LORA_Q | TTL_LORA_V)) == (b.lora_targets ? b.lora_targets : (TTL_LORA_Q | TTL_LORA_V));
+}
+
+static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) {
     if (!out) return fail(TTL_EINVAL, "null out");
     *out = nullptr;
     int rc = check_config(k);
     if (rc) return rc;
+    if (parent) {
+        if (parent->parent) return fail(TTL_EINVAL, "the parent of a shared context must own its weights");
+        if (!same_model(*k, parent->c)) return fail(TTL_EINVAL, "a shared context needs the parent's model configuration (capacities may differ)");
+        if ((rc = ttl_weights_ready(parent))) return rc;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(e != hipSuccess ? (int)e : TTL_ESTATE, "no HIP device available (%s)", hipGetErrorString(e));
     ttl_ctx* c = new ttl_ctx();
     set_geometry(c, k);
+    c->parent = parent;
     const size_t D = c->D, F = c->F, M = c->Mmax, E = c->E, N = k->max_views, T = c->T, H = c->H, r = c->r;
+    // frozen tensor: the parent's image (never written after loading) or an allocation of this context's own
+#define WSHARE(dst, src, count, zero) do { if (parent) (dst) = (src); else ALLOC(dst, count, zero); } while (0)
     struct Guard { ttl_ctx* c; bool ok = false; ~Guard() { if (!ok) ttl_ctx_destroy(c); } } guard{c};
+    {   // head-major q/k/v: needs row / T by multiply-high for every row a big-M launch can store
+        const char* v = getenv("TTL_QKV_HEAD_MAJOR");
+        c->hm_magic = qkv_hm_magic((int)T, (int)M + 320);
+        c->use_hm = (v ? atoi(v) != 0 : 1) && c->hm_magic != 0;
+    }
     c->layers.resize(c->L);
     for (int i = 0; i < c->L; ++i) {
         Layer& l = c->layers[i];
@@ -272,38 +309,55 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
         l.trained = (i >= k->layer_lo);
         l.lora = (i >= k->layer_lo && i <= k->layer_hi);
         l.ldwo = l.ldat = (int)D + ((l.lora && c->has_o) ? 64 : 0);
-        ALLOC(l.wqkv, 3 * D * c->ldw, true); ALLOC(l.bqkv, 3 * D, true);
-        ALLOC(l.wo, D * l.ldwo, true); ALLOC(l.bo, D, true);
-        ALLOC(l.w1, F * D, false); ALLOC(l.b1, F, true);
-        ALLOC(l.w2, D * F, false); ALLOC(l.b2, D, true);
-        ALLOC(l.ln1g, D, true); ALLOC(l.ln1b, D, true); ALLOC(l.ln2g, D, true); ALLOC(l.ln2b, D, true);
+        const Layer* pl = parent ? &parent->layers[i] : nullptr;
+        // the projection images of a layer WITH adapters carry the LoRA K-extension columns, which every context refreshes from
+        // its own adapters: private, initialised from the parent's below.  Everything else of a layer is frozen for good.
+        const bool own_proj = l.lora || !parent;
+        if (own_proj) { ALLOC(l.wqkv, 3 * D * c->ldw, true); ALLOC(l.wo, D * l.ldwo, true); }
+        else { l.wqkv = pl->wqkv; l.wo = pl->wo; }
+        WSHARE(l.bqkv, pl->bqkv, 3 * D, true); WSHARE(l.bo, pl->bo, D, true);
+        WSHARE(l.w1, pl->w1, F * D, false); WSHARE(l.b1, pl->b1, F, true);
+        WSHARE(l.w2, pl->w2, D * F, false); WSHARE(l.b2, pl->b2, D, true);
+        WSHARE(l.ln1g, pl->ln1g, D, true); WSHARE(l.ln1b, pl->ln1b, D, true); WSHARE(l.ln2g, pl->ln2g, D, true); WSHARE(l.ln2b, pl->ln2b, D, true);
         if (l.trained) {
-            ALLOC(l.wqkvT, D * c->ldwt, true); ALLOC(l.woT, D * l.ldwo, true); ALLOC(l.w1T, D * F, false); ALLOC(l.w2T, F * D, false);
+            if (own_proj) { ALLOC(l.wqkvT, D * c->ldwt, true); ALLOC(l.woT, D * l.ldwo, true); }
+            else { l.wqkvT = pl->wqkvT; l.woT = pl->woT; }
+            WSHARE(l.w1T, pl->w1T, D * F, false); WSHARE(l.w2T, pl->w2T, F * D, false);
+            if (parent && l.lora) {
+                HIP_TRY(hipMemcpy(l.wqkv, pl->wqkv, 3 * D * c->ldw * sizeof(op_t), hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy(l.wo, pl->wo, D * l.ldwo * sizeof(op_t), hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy(l.wqkvT, pl->wqkvT, D * c->ldwt * sizeof(op_t), hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy(l.woT, pl->woT, D * l.ldwo * sizeof(op_t), hipMemcpyDeviceToDevice));
+            }
             ALLOC(l.acat, 3 * r * D, true); ALLOC(l.btcat, 3 * r * D, true); ALLOC(l.acat_o, r * D, true); ALLOC(l.btcat_o, r * D, true);
             ALLOC(l.h_mid, M * D, false);  // h_in is a pointer into the stream buffers
-            ALLOC(l.x1ext, M * c->ldx, true); ALLOC(l.qkv, M * 3 * D, false); ALLOC(l.attn, M * l.ldat, true); ALLOC(l.u, M * F, false);
+            ALLOC(l.x1ext, M * c->ldx, true); ALLOC(l.qkv, (M + T) * 3 * D, false); ALLOC(l.attn, M * l.ldat, true); ALLOC(l.u, M * F, false);
             ALLOC(l.lse, N * H * T, false);
             ALLOC(l.mu1, M, false); ALLOC(l.rs1, M, false); ALLOC(l.mu2, M, false); ALLOC(l.rs2, M, false);
         }
     }
-    ALLOC(c->wpatch, D * c->Kp, true);
+    if (parent) for (int i = 0; i < c->L; ++i) c->layers[i].loaded = W_ALL;
+    WSHARE(c->wpatch, parent->wpatch, D * c->Kp, true);
     if (c->text) {
-        ALLOC(c->tok, (size_t)k->vocab_size * D, false);
+        WSHARE(c->tok, parent->tok, (size_t)k->vocab_size * D, false);
         ALLOC(c->ids, N * T, true); ALLOC(c->pool, N, true); ALLOC(c->poolrows, N, true);
         ALLOC(c->hpool, N * D, true); ALLOC(c->hmid_g, N * D, false); ALLOC(c->mu2_g, N, false); ALLOC(c->rs2_g, N, false);
         ALLOC(c->u_g, N * F, false);
         ALLOC(c->logits_nk, N * k->max_classes, false); ALLOC(c->dlogits_nk, N * k->max_classes, false);
         ALLOC(c->dlogits_kn, N * k->max_classes, false);
     }
-    ALLOC(c->cls, D, true); ALLOC(c->pos, T * D, true);
-    ALLOC(c->preg, D, true); ALLOC(c->preb, D, true); ALLOC(c->postg, D, true); ALLOC(c->postb, D, true);
-    ALLOC(c->wp, E * D, true); ALLOC(c->wpT, D * E, true);
+    WSHARE(c->cls, parent->cls, D, true); WSHARE(c->pos, parent->pos, T * D, true);
+    WSHARE(c->preg, parent->preg, D, true); WSHARE(c->preb, parent->preb, D, true); WSHARE(c->postg, parent->postg, D, true); WSHARE(c->postb, parent->postb, D, true);
+    WSHARE(c->wp, parent->wp, E * D, true); WSHARE(c->wpT, parent->wpT, D * E, true);
+    if (parent) c->head_loaded = parent->head_loaded;
+#undef WSHARE
     ALLOC(c->tfeat, (size_t)k->max_classes * E, true); ALLOC(c->tfeatT, (size_t)k->max_classes * E, true);
     ALLOC(c->patches, N * c->G2 * c->Kp, true);
     ALLOC(c->h, M * D, false);
     c->h_out.assign(c->nS, nullptr);
     for (int i = 0; i < c->nS; ++i) ALLOC(c->h_out[i], M * D, false);
-    ALLOC(c->x1, M * D, false); ALLOC(c->qkv, M * 3 * D, false); ALLOC(c->attn, M * D, false);
+    // (q/k/v buffers: + T rows, the head-major image of the padding rows of the last row tile spills into one more view's block)
+    ALLOC(c->x1, M * D, false); ALLOC(c->qkv, (M + T) * 3 * D, false); ALLOC(c->attn, M * D, false);
     ALLOC(c->x2, M * D, false); ALLOC(c->g, M * F, false);
     ALLOC(c->cls_mean, N, false); ALLOC(c->cls_rstd, N, false); ALLOC(c->ycls, N * D, false); ALLOC(c->feat, N * E, false);
     ALLOC(c->logits, N * k->max_classes, false); ALLOC(c->dlogits, N * k->max_classes, false);
@@ -331,6 +385,13 @@ int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) {
     guard.ok = true;
     *out = c;
     return 0;
+}
+
+int ttl_ctx_create(const ttl_config* k, ttl_ctx** out) { return ctx_create_impl(k, nullptr, out); }
+
+int ttl_ctx_create_shared(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) {
+    if (!parent) return fail(TTL_EINVAL, "null parent");
+    return ctx_create_impl(k, parent, out);
 }
 
 void ttl_ctx_destroy(ttl_ctx* c) {
@@ -386,6 +447,7 @@ int ttl_load_weight_typed(ttl_ctx* c, const char* name, const void* data, size_t
 
 int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t count) {
     if (!c || !name || !data) return fail(TTL_EINVAL, "null argument");
+    if (c->parent) return fail(TTL_ESTATE, "%s: this context shares its parent's weights (ttl_ctx_create_shared); load them into the parent", name);
     const size_t D = c->D, F = c->F, E = c->E, T = c->T;
     float* tmp = nullptr;
     int rc = 0;
@@ -679,8 +741,9 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             }
             {
                 Prof p(c, 1, s);
-                HIP_TRY(launch_attention_fwd_cls(qkv, 3 * D, att, ldat, sv ? l.lse : nullptr, n, T, H, s, c->text ? c->pool : nullptr, causal));
+                HIP_TRY(launch_attention_fwd_cls(qkv, qkv_row_major(T, D, 3 * D), att, ldat, sv ? l.lse : nullptr, n, T, H, s, c->text ? c->pool : nullptr, causal));
             }
+            l.qkv_hm = false;   // (K/V by a big-M launch into columns D.., Q of the pooled rows by a small-M one: row-major)
             if (lo_o) {   // out_proj adapter: U_o = s * attn * A_o^T into the extension columns of the pooled rows
                 Prof p(c, 4, s);
                 const int xoff[3] = {0, 0, 0};
@@ -715,15 +778,18 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             h = h_next;
             continue;
         }
+        bool hm = false;
         {
             GemmArgs a = {};
             a.A = x1; a.lda = ldx1; a.B = l.wqkv; a.ldb = c->ldw; a.M = M; a.N = 3 * D; a.K = lo_qkv ? D + c->ext : D;
             a.C = qkv; a.ldc = 3 * D; a.bias = l.bqkv;
+            hm = qkv_goes_head_major(c, a);
             if ((rc = gemm(c, EPI_OP, a, s))) return rc;
         }
+        if (tr) l.qkv_hm = hm;
         {
             Prof p(c, 1, s);
-            HIP_TRY(launch_attention_fwd(qkv, 3 * D, att, ldat, sv ? l.lse : nullptr, n, T, H, s, causal));
+            HIP_TRY(launch_attention_fwd(qkv, hm ? qkv_head_major(T, H) : qkv_row_major(T, D, 3 * D), att, ldat, sv ? l.lse : nullptr, n, T, H, s, causal));
         }
         if (lo_o) {
             Prof p(c, 4, s);
@@ -939,8 +1005,8 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd_cls(l.qkv, 3 * D, l.attn, l.ldat, c->doc, l.lse, c->dqkv, c->ldwt, n, T, H, need_dk, s,
-                                                 pool, causal));
+                HIP_TRY(launch_attention_bwd_cls(l.qkv, l.qkv_hm ? qkv_head_major(T, H) : qkv_row_major(T, D, 3 * D), l.attn, l.ldat, c->doc, l.lse,
+                                                 c->dqkv, c->ldwt, n, T, H, need_dk, s, pool, causal));
             }
             dres_cls = c->dhmc;
         } else {
@@ -978,7 +1044,8 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
             }
             {
                 Prof p(c, 2, s);
-                HIP_TRY(launch_attention_bwd(l.qkv, 3 * D, l.attn, c->dattn, l.ldat, l.lse, c->dqkv, c->ldwt, n, T, H, need_dk, s, causal));
+                HIP_TRY(launch_attention_bwd(l.qkv, l.qkv_hm ? qkv_head_major(T, H) : qkv_row_major(T, D, 3 * D), l.attn, c->dattn, l.ldat, l.lse,
+                                             c->dqkv, c->ldwt, n, T, H, need_dk, s, causal));
             }
             dres_cls = nullptr;
         }
@@ -1246,13 +1313,13 @@ int ttl_cast_f32_operand(const float* src, void* dst, size_t n, void* stream) {
 }
 
 int ttl_attention_fwd(const void* qkv, void* out, float* lse, int n, int T, int H, int causal, void* stream) {
-    HIP_TRY(launch_attention_fwd((const op_t*)qkv, 3 * H * 64, (op_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream, causal));
+    HIP_TRY(launch_attention_fwd((const op_t*)qkv, qkv_row_major(T, H * 64, 3 * H * 64), (op_t*)out, H * 64, lse, n, T, H, (hipStream_t)stream, causal));
     return 0;
 }
 
 int ttl_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int ld_dqkv, int n, int T,
                       int H, int need_dk, int causal, void* stream) {
-    HIP_TRY(launch_attention_bwd((const op_t*)qkv, 3 * H * 64, (const op_t*)out, (const op_t*)dout, H * 64, lse, (op_t*)dqkv,
+    HIP_TRY(launch_attention_bwd((const op_t*)qkv, qkv_row_major(T, H * 64, 3 * H * 64), (const op_t*)out, (const op_t*)dout, H * 64, lse, (op_t*)dqkv,
                                  ld_dqkv, n, T, H, need_dk, (hipStream_t)stream, causal));
     return 0;
 }
@@ -1305,6 +1372,18 @@ int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t by
         else return fail(TTL_EINVAL, "unknown buffer %s", name);
     }
     if (bytes > have) return fail(TTL_EINVAL, "%s holds %zu bytes, %zu requested", name, have, bytes);
+    if (nm == "qkv" && c->layers[layer].qkv_hm) {
+        // the caller sees q/k/v row-major [n*T][3D] whatever layout the forward used: un-permute the head-major image on the host
+        std::vector<op_t> raw(M * 3 * D);
+        HIP_TRY(hipMemcpy(raw.data(), src, raw.size() * sizeof(op_t), hipMemcpyDeviceToHost));
+        const size_t T = c->T, H = c->H, nel = bytes / sizeof(op_t);
+        op_t* out = (op_t*)dst;
+        for (size_t e = 0; e < nel; ++e) {
+            const size_t m = e / (3 * D), col = e % (3 * D), v = m / T, t = m % T, pl = col / D, hd = (col % D) / 64, d = col % 64;
+            out[e] = raw[((v * 3 + pl) * H + hd) * T * 64 + t * 64 + d];
+        }
+        return 0;
+    }
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -94,7 +94,7 @@ constexpr float SCALE = 0.125f;  // head_dim^-0.5, head_dim = 64
 
 // ------------------------------------------------------------------------------ forward
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out,
                                                        int ldo, float* __restrict__ lse, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32;
@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
-    stage_tile<NKT>(sK, qg + D, ld, T, tid, wave);
-    stage_tile<NKT>(sV, qg + 2 * D, ld, T, tid, wave);
+    const int ld = L.tok;
+    const op_t* qg = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kg = qg + L.k_off, *vg = qg + L.v_off;
+    stage_tile<NKT>(sK, kg, ld, T, tid, wave);
+    stage_tile<NKT>(sV, vg, ld, T, tid, wave);
     __syncthreads();
 
     const int nqb = (T + 31) >> 5;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op_t* __restrict__ 
 // wave needs ~125 VGPRs (the whole-row version needs 256): two 7-wave workgroups per CU = 3.5 waves
 // per SIMD hide the LDS / exp latency that the 4-wave version (2 per SIMD) exposed.
 template <int NKT, int CH>
-__global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out,
                                                              int ldo, float* __restrict__ lse, int T, int H, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32, NTHR = 64 * NKT;
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const int ld = L.tok;
+    const op_t* qg = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kg = qg + L.k_off, *vg = qg + L.v_off;
     // this wave's Q fragments first: their latency hides under the K/V staging
     const int q = wave * 32 + (lane & 31);
     const int qrow = min(q, T - 1);
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
         int c16 = i * NTHR + tid, r = c16 >> 3, p = c16 & 7;
         int c = p ^ swz(r);
         size_t go = (size_t)min(r, T - 1) * ld + c * 8;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(qg + D + go), LDS_PTR(sK + (i * NTHR + wave * 64) * 16), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(qg + 2 * D + go), LDS_PTR(sV + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(kg + go), LDS_PTR(sK + (i * NTHR + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(vg + go), LDS_PTR(sV + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
     __syncthreads();
     if (wave * 32 >= T) return;   // (never for NKT = ceil(T/32); kept for safety — after the only barrier)
@@ -307,13 +309,13 @@ __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) 
 // matrix phases: no change (0.308-0.312): what is left is the rate the q/k/v segments arrive at.  Giving the workgroups of XCD x
 // the views whose q/k/v rows XCD x's tiles of the QKV GEMM have just written (producer / consumer on the same L2): no change either.
 template <int NKT, int CH>
-__global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out,
                                                              int ldo, float* __restrict__ lse, int T, int H, int nprob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32, NTHR = 64 * NKT, TILE = TP * 128, BUF = 2 * TILE, QOFF = 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = H * 64;
+    const int ld = L.tok;
     const int h = lane >> 5, l31 = lane & 31;
     // row-read offsets of the K tile (row l31 of a 32-row block, 16-B chunk 2*ks + h); the q rows of this wave likewise
     int koff[4];
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
             const int c16 = i * NTHR + tid, r = c16 >> 3, pz = c16 & 7;
             const int c = pz ^ swz(r);
             const size_t go = (size_t)min(r, T - 1) * ld + c * 8;
-            dma16_untracked(qg + D + go, buf + (i * NTHR + wave * 64) * 16);
-            dma16_untracked(qg + 2 * D + go, buf + TILE + (i * NTHR + wave * 64) * 16);
+            dma16_untracked(qg + L.k_off + go, buf + (i * NTHR + wave * 64) * 16);
+            dma16_untracked(qg + L.v_off + go, buf + TILE + (i * NTHR + wave * 64) * 16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
     const int q = wave * 32 + l31;
     int p = blockIdx.x;
     int img = p / H, head = p - img * H;
-    stage(qkv + (size_t)img * T * ld + head * 64, smem);
+    stage(qkv + (size_t)img * L.view + (size_t)head * L.head, smem);
 
     constexpr float C2 = SCALE * 1.4426950408889634f;
     for (int it = 0;; ++it) {
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
         if (more) {
             imgn = pn / H; headn = pn - imgn * H;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (TTL_ATTN_DIAG != 2) stage(qkv + (size_t)imgn * T * ld + headn * 64, smem + (boff ^ BUF));
+            if (TTL_ATTN_DIAG != 2) stage(qkv + (size_t)imgn * L.view + (size_t)headn * L.head, smem + (boff ^ BUF));
         }
         int kb[4], vb[2][2];
 #pragma unroll
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
 
 // ------------------------------------------------------------------------------ backward: dQ
 template <int NKT, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, int ld,
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __restrict__ qkv, const QkvLayout L,
                                                           const op_t* __restrict__ out, const op_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse,
                                                           op_t* __restrict__ dqkv, int ldd, int T, int H, int causal) {
@@ -475,12 +477,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const int ld = L.tok;
+    const op_t* qg = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kg = qg + L.k_off, *vg = qg + L.v_off;
     const op_t* og = out + (size_t)img * T * ldo + head * 64;
     const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
-    stage_tile<NKT, NW>(sK, qg + D, ld, T, tid, wave);
-    stage_tile<NKT, NW>(sV, qg + 2 * D, ld, T, tid, wave);
+    stage_tile<NKT, NW>(sK, kg, ld, T, tid, wave);
+    stage_tile<NKT, NW>(sV, vg, ld, T, tid, wave);
     __syncthreads();
 
     const int nqb = (T + 31) >> 5;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
 
 // ------------------------------------------------------------------------------ backward: dK, dV
 template <int NKT, bool NEED_DK, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __restrict__ qkv, int ld,
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __restrict__ qkv, const QkvLayout L,
                                                            const op_t* __restrict__ out,
                                                            const op_t* __restrict__ dout, int ldo,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv,
@@ -544,8 +547,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* qg = qkv + (size_t)img * T * ld + head * 64;
+    const int ld = L.tok;
+    const op_t* qg = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kg = qg + L.k_off, *vg = qg + L.v_off;
     const op_t* og = out + (size_t)img * T * ldo + head * 64;
     const op_t* dog = dout + (size_t)img * T * ldo + head * 64;
     stage_tile<NKT, NW>(sQ, qg, ld, T, tid, wave);
@@ -572,8 +576,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
         opx8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = global_frag(qg + D, ld, krow, ks, lane);
-            vf[ks] = global_frag(qg + 2 * D, ld, krow, ks, lane);
+            kf[ks] = global_frag(kg, ld, krow, ks, lane);
+            vf[ks] = global_frag(vg, ld, krow, ks, lane);
         }
         f32x16 dv[2] = {}, dk[2] = {};
 #pragma unroll 1
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
             }
         }
         if (key < T) {
+            const int D = H * 64;     // dqkv is row-major [tokens][dq | dk | dv | ...]: the A operand of the dX GEMM
             op_t* base = dqkv + (size_t)(img * T + key) * ldd + head * 64;
             store_ot(base + 2 * D, dv, 1.0f, lane);
             if (NEED_DK) store_ot(base + D, dk, SCALE, lane);
@@ -618,15 +623,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
 // Last encoder layer of the image tower: only its CLS row reaches the head, so only query 0 of every (view, head)
 // is needed: o_0 = softmax(q_0 K^T / 8) V.  Same rounding points as the dense kernel (P rounded to the operand type
 // before the PV product, row sum taken before rounding); writes row 0 of `out` and lse[.., 0] in place.
-__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restrict__ qkv, int ld, op_t* __restrict__ out, int ldo,
+__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out, int ldo,
                                                            float* __restrict__ lse, int T, int H, const int* __restrict__ qpos,
                                                            int causal) {
     __shared__ float sq[64], sp[320], sred[32][64];
     __shared__ float smax[4], ssum[4];
     const int tid = threadIdx.x;
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* base = qkv + (size_t)img * T * ld + head * 64;
+    const int ld = L.tok;
+    const op_t* base = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kbase = base + L.k_off, *vbase = base + L.v_off;
     const int qp = qpos ? qpos[img] : 0;              // the pooled query: CLS, or the end-of-text token (text tower)
     const int Tk = causal ? qp + 1 : T;               // keys it can see
     if (tid < 64) sq[tid] = op_to_f32(base[(size_t)qp * ld + tid]);
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
     for (int j0 = 0; j0 < Tk; j0 += 32) {
         const int j = j0 + grp;
         const int jr = j < Tk ? j : Tk - 1;
-        opx8 kf = *(const opx8*)(base + (size_t)jr * ld + D + 8 * c);
+        opx8 kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(qc[e], (float)kf[e], s);
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
             const float pj = __expf((sp[j] - mx) * SCALE);
             if (c == 0) sum += pj;
             const float pb = op_to_f32(f32_to_op(pj));
-            opx8 vf = *(const opx8*)(base + (size_t)j * ld + 2 * D + 8 * c);
+            opx8 vf = *(const opx8*)(vbase + (size_t)j * ld + 8 * c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, (float)vf[e], o[e]);
         }
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
 //   p_j = exp(q0.k_j/8 - lse0), dp_j = do0.v_j, ds_j = p_j (dp_j - do0.o0),
 //   dq_0 = sum_j ds_j k_j / 8,  dk_j = ds_j q0 / 8,  dv_j = p_j do0;   dq_t = 0 for t > 0.
 template <bool NEED_DK>
-__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restrict__ qkv, int ld, const op_t* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restrict__ qkv, const QkvLayout L, const op_t* __restrict__ out,
                                                            int ldo, const op_t* __restrict__ dout_cls,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv, int ldd,
                                                            int T, int H, const int* __restrict__ qpos, int causal) {
@@ -698,8 +704,10 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
     __shared__ float sdelta;
     const int tid = threadIdx.x;
     const int img = blockIdx.x / H, head = blockIdx.x - img * H;
-    const int D = H * 64;
-    const op_t* base = qkv + (size_t)img * T * ld + head * 64;
+    const int ld = L.tok;
+    const op_t* base = qkv + (size_t)img * L.view + (size_t)head * L.head;
+    const op_t *kbase = base + L.k_off, *vbase = base + L.v_off;
+    const int D = H * 64;                  // (dout_cls and dqkv are row-major)
     const int qp = qpos ? qpos[img] : 0;   // the one query with a non-zero d(out): CLS, or end-of-text
     if (tid < 64) {
         sq[tid] = op_to_f32(base[(size_t)qp * ld + tid]);
@@ -719,8 +727,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
         const int j = j0 + grp;
         const bool ok = j < T;
         const int jr = ok ? j : T - 1;
-        opx8 kf = *(const opx8*)(base + (size_t)jr * ld + D + 8 * c);
-        opx8 vf = *(const opx8*)(base + (size_t)jr * ld + 2 * D + 8 * c);
+        opx8 kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
+        opx8 vf = *(const opx8*)(vbase + (size_t)jr * ld + 8 * c);
         float s = 0.f, dp = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s = fmaf(qc[e], (float)kf[e], s); dp = fmaf(dc[e], (float)vf[e], dp); }
@@ -758,44 +766,34 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
     }
 }
 
-template <typename K>
-hipError_t set_smem(K kernel, int bytes) {
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
 
 template <int NKT, int CH>
-hipError_t fwd_w(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
+hipError_t fwd_w(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
-    static std::atomic<bool> done{false};
-    if (!done.load()) { hipError_t e = set_smem(attn_fwd_w_kernel<NKT, CH>, SMEM); if (e != hipSuccess) return e; done.store(true); }
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_smem((const void*)attn_fwd_w_kernel<NKT, CH>, SMEM, done); e != hipSuccess) return e;
     hipLaunchKernelGGL((attn_fwd_w_kernel<NKT, CH>), dim3(n * H), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
 
 template <int NKT, int CH>
-hipError_t fwd_p(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+hipError_t fwd_p(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
     constexpr int SMEM = 5 * NKT * 32 * 128;     // two (K, V) pairs + q
-    static std::atomic<bool> done{false};
-    static std::atomic<int> ncu{0};
-    if (!done.load()) {
-        hipError_t e = set_smem(attn_fwd_p_kernel<NKT, CH>, SMEM);
-        if (e != hipSuccess) return e;
-        int dev = 0; hipDeviceProp_t pr;
-        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&pr, dev)) != hipSuccess) return e;
-        ncu.store(pr.multiProcessorCount);
-        done.store(true);
-    }
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_smem((const void*)attn_fwd_p_kernel<NKT, CH>, SMEM, done); e != hipSuccess) return e;
+    const int cus = device_cu_count();
+    if (!cus) return hipErrorInvalidDevice;
     const int nprob = n * H;
-    const int grid = nprob < ncu.load() ? nprob : ncu.load();
+    const int grid = nprob < cus ? nprob : cus;
     hipLaunchKernelGGL((attn_fwd_p_kernel<NKT, CH>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob);
     return hipGetLastError();
 }
 
 template <int NKT>
-hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
+hipError_t fwd_t(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s, int causal) {
     constexpr int SMEM = 2 * NKT * 32 * 128;
-    static std::atomic<bool> done{false};
-    if (!done.load()) { hipError_t e = set_smem(attn_fwd_kernel<NKT>, SMEM); if (e != hipSuccess) return e; done.store(true); }
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_smem((const void*)attn_fwd_kernel<NKT>, SMEM, done); e != hipSuccess) return e;
     hipLaunchKernelGGL((attn_fwd_kernel<NKT>), dim3(n * H), dim3(256), SMEM, s, qkv, ld, out, ldo, lse, T, H, causal);
     return hipGetLastError();
 }
@@ -807,7 +805,7 @@ hipError_t fwd_t(const op_t* qkv, int ld, op_t* out, int ldo, float* lse, int n,
 #define TTL_ATTN_NW_DKV 0
 #endif
 template <int NKT>
-hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
+hipError_t bwd_t(const op_t* qkv, QkvLayout ld, const op_t* out, const op_t* dout, int ldo, const float* lse,
                  op_t* dqkv, int ldd, int n, int T, int H, int need_dk, hipStream_t s, int causal) {
     // waves per (sequence, head) block: 0 = one per 32-row block (NKT waves; used), or a fixed count.  In situ on
     // ViT-B/16 (tools/attn_ab.sh, attention-backward ms per episode): 4/4 waves 0.273, NKT/4 0.229, 8/8 0.222, NKT/NKT 0.205
@@ -815,14 +813,11 @@ hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int
     constexpr int NWK = (TTL_ATTN_NW_DKV == 0) ? NKT : TTL_ATTN_NW_DKV;
     constexpr int SMEM_A = 2 * NKT * 32 * 128;
     constexpr int SMEM_B = 2 * NKT * 32 * 128 + 2 * NKT * 32 * 4;
-    static std::atomic<bool> done{false};
-    if (!done.load()) {
-        hipError_t e = set_smem(attn_bwd_dq_kernel<NKT, NWQ>, SMEM_A);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, true, NWK>, SMEM_B);
-        if (e == hipSuccess) e = set_smem(attn_bwd_dkv_kernel<NKT, false, NWK>, SMEM_B);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    static std::atomic<uint64_t> done_q{0}, done_k{0}, done_v{0};
+    hipError_t e = ensure_smem((const void*)attn_bwd_dq_kernel<NKT, NWQ>, SMEM_A, done_q);
+    if (e == hipSuccess) e = ensure_smem((const void*)attn_bwd_dkv_kernel<NKT, true, NWK>, SMEM_B, done_k);
+    if (e == hipSuccess) e = ensure_smem((const void*)attn_bwd_dkv_kernel<NKT, false, NWK>, SMEM_B, done_v);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NKT, NWQ>), dim3(n * H), dim3(64 * NWQ), SMEM_A, s, qkv, ld, out, dout, ldo, lse, dqkv,
                        ldd, T, H, causal);
     if (need_dk)
@@ -836,7 +831,7 @@ hipError_t bwd_t(const op_t* qkv, int ld, const op_t* out, const op_t* dout, int
 
 }  // namespace
 
-hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
+hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                 hipStream_t s, int causal) {
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
@@ -858,7 +853,7 @@ hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_o
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
+hipError_t launch_attention_bwd(const op_t* qkv, QkvLayout ld_qkv, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s, int causal) {
     int nkt = (T + 31) / 32;
@@ -870,14 +865,14 @@ hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, co
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
+hipError_t launch_attention_fwd_cls(const op_t* qkv, QkvLayout ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                     hipStream_t s, const int* qpos, int causal) {
     if (T > 320) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H, qpos, causal);
     return hipGetLastError();
 }
 
-hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
+hipError_t launch_attention_bwd_cls(const op_t* qkv, QkvLayout ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s, const int* qpos, int causal) {
     if (need_dk)

@@ -265,18 +265,8 @@ template <int BM, int WMW, int WNW, int EPI, bool GUARD = true, int STAGES = 2>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BN = 64 * WNW;
     constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
-    {   // once per (kernel, device); thread-safe
-        static std::atomic<uint64_t> done{0};
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        const uint64_t bit = 1ull << (dev & 63);
-        if (!(done.load(std::memory_order_acquire) & bit)) {
-            e = hipFuncSetAttribute((const void*)gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-            if (e != hipSuccess) return e;
-            done.fetch_or(bit, std::memory_order_release);
-        }
-    }
+    static std::atomic<uint64_t> done{0};     // once per (kernel, device)
+    if (hipError_t e = ensure_smem((const void*)gemm_kernel<BM, WMW, WNW, STAGES, EPI, GUARD>, SMEM, done); e != hipSuccess) return e;
     if (a.N % BN) return hipErrorInvalidValue;
     int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     GemmArgs b = a;
@@ -348,6 +338,11 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+bool gemm_takes_big(GemmEpi epi, const GemmArgs& a) {
+    static const bool use_big = [] { const char* v = getenv("TTL_GEMM_BIG"); return v ? atoi(v) != 0 : true; }();
+    return use_big && a.padded && gemm_big_applicable(epi, a) && (size_t)((a.M + 159) / 160) * 160 <= (size_t)a.padded;
+}
+
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     if (a0.M <= 0 || a0.N % 128 || a0.K % BK || a0.K <= 0 || (a0.lda & 7) || (a0.ldb & 7)) return hipErrorInvalidValue;
     if ((a0.amap || a0.cmap || a0.c2map) && a0.M >= 1024) return hipErrorInvalidValue;   // row maps: guarded small-M kernels only
@@ -369,9 +364,8 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
         }
     }
     // big-M launches: 256-column tiles (gemm_big.hip) unless switched off (TTL_GEMM_BIG=0: the 160x128 kernel below)
-    static const bool use_big = [] { const char* v = getenv("TTL_GEMM_BIG"); return v ? atoi(v) != 0 : true; }();
-    if (use_big && a.padded && gemm_big_applicable(epi, a) && (size_t)((a.M + 159) / 160) * 160 <= (size_t)a.padded)
-        return launch_gemm_big(epi, a, s);
+    if (gemm_takes_big(epi, a)) return launch_gemm_big(epi, a, s);
+    if (a.hm_T) return hipErrorInvalidValue;   // head-major q/k/v output exists in the big-M epilogue only (ask gemm_takes_big first)
     switch (epi) {
         case EPI_F32: return launch_v<EPI_F32>(a, s);
         case EPI_OP: return launch_v<EPI_OP>(a, s);

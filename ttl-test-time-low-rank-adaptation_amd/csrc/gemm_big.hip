@@ -107,15 +107,30 @@ __device__ __forceinline__ void wait_dma() {
 // operations here are stores (an ordinary load next to the next tile's in-flight LDS-DMA makes hipcc wait vmcnt(0),
 // which drains that prefetch).  Register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column 4*li + nt.
 constexpr int EPI_GELU_C2 = 100;   // internal: EPI_GELU with the second (pre-activation) output, kept branch-free
+constexpr int EPI_OP_HM = 101;     // internal: EPI_OP into a head-major q/k/v buffer (GemmArgs::hm_T, kernels.hpp QkvLayout)
+
+// Head-major q/k/v (EPI_OP_HM): the lane's 4 columns n0..n0+3 lie in one head, so their offset inside a view's block is a
+// per-tile constant (hm_col_base, computed once per tile) and a row adds view*3*D*T + t*64 with view = m / T by a multiply-high
+// (magic checked on the host for every row a launch can store).  Per (mt, r) a 16-lane group still writes one whole 128-B
+// line — row t of the (view, plane, head) tile — and consecutive tokens are now ADJACENT lines.
+__device__ __forceinline__ size_t hm_col_base(const GemmArgs& a, int n0) {
+    const int Dm = a.N / 3;
+    const int plane = (n0 >= Dm) + (n0 >= 2 * Dm);
+    const int rem = n0 - plane * Dm;
+    return ((size_t)plane * Dm + (size_t)(rem & ~63)) * a.hm_T + (rem & 63);
+}
 
 template <int EPI, int MT>
-__device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 (&acc)[MT][4], int mt, int rbase, int n0, int lg) {
+__device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 (&acc)[MT][4], int mt, int rbase, size_t n0, int lg) {
     {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t m = (size_t)(rbase + mt * 16 + 4 * lg + r);
             float v0 = acc[mt][0][r], v1 = acc[mt][1][r], v2 = acc[mt][2][r], v3 = acc[mt][3][r];
-            if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
+            if constexpr (EPI == EPI_OP_HM) {
+                const unsigned view = __umulhi((unsigned)m, a.hm_magic), t = (unsigned)m - view * (unsigned)a.hm_T;
+                st_out((u32x2*)((op_t*)a.C + (size_t)view * a.N * a.hm_T + n0 + (size_t)t * 64), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
+            } else if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
                 st_out((f32x4*)((float*)a.C + m * a.ldc + n0), f32x4{v0, v1, v2, v3});
             } else {
                 if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_C2) {
@@ -131,7 +146,7 @@ __device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 
 }
 
 template <int EPI, int MT>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, int n0, int lg) {
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, size_t n0, int lg) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) big_epilogue_row<EPI, MT>(a, acc, mt, rbase, n0, lg);
 }
@@ -379,6 +394,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             Mix<0, MT + 4, 0, 4 * MT>::run();
             __builtin_amdgcn_sched_barrier(0);
             load_frags(nxt, 1, xf1, wf1);
+            size_t ecol = (size_t)(ecol0 + wn * 64 + 4 * li);      // column argument of the epilogue (EPI_OP_HM: offset inside a view's block)
+            if constexpr (EPI == EPI_OP_HM) ecol = hm_col_base(a, (int)ecol);
             if constexpr (TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -386,9 +403,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf0[mt], wf0[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf1[mt], wf1[nt], acc[mt][nt], 0, 0, 0);
-                    if (mt > 0) big_epilogue_row<EPI, MT>(a, acc, mt - 1, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+                    if (mt > 0) big_epilogue_row<EPI, MT>(a, acc, mt - 1, erow0 + wm * WM, ecol, lg);
                 }
-                big_epilogue_row<EPI, MT>(a, acc, MT - 1, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+                big_epilogue_row<EPI, MT>(a, acc, MT - 1, erow0 + wm * WM, ecol, lg);
             } else {
                 mma(xf0, wf0);
                 mma(xf1, wf1);
@@ -399,7 +416,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
-        } else if (!(TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0)) big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol0 + wn * 64 + 4 * li, lg);
+        } else if (!(TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0)) {
+            size_t ecol = (size_t)(ecol0 + wn * 64 + 4 * li);
+            if constexpr (EPI == EPI_OP_HM) ecol = hm_col_base(a, (int)ecol);
+            big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol, lg);
+        }
         if (!more) break;
         slot = nslot;
         first = false;
@@ -408,19 +429,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
         if constexpr (STAGES == 3) { s0 = cur; s1 = nn; s2 = nxt; }
         else { s0 = cur; s1 = nxt; }
     }
-}
-
-// hipFuncSetAttribute once per (kernel, device); thread-safe
-inline hipError_t ensure_smem(const void* fn, int bytes, std::atomic<uint64_t>& done) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    done.fetch_or(bit, std::memory_order_release);
-    return hipSuccess;
 }
 
 int env_int(const char* name, int dflt) {
@@ -456,6 +464,15 @@ hipError_t launch_big_v(const GemmArgs& a, int mt, int stages, int order, int ma
 
 }  // namespace
 
+unsigned qkv_hm_magic(int T, int limit) {
+    if (T < 1 || limit < 1) return 0;
+    const uint64_t magic = (1ull << 32) / (uint64_t)T + 1;
+    if (magic >> 32) return 0;                                    // T == 1
+    for (uint64_t m = 0; m < (uint64_t)limit; ++m)
+        if (((m * magic) >> 32) != m / (uint64_t)T) return 0;
+    return (unsigned)magic;
+}
+
 // rows the kernel may store for a launch of M rows with row tiles of 32*mt (unguarded epilogue)
 bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
     if (epi == EPI_PATCH) return false;                       // scattered output rows: guarded kernel of gemm.hip
@@ -473,13 +490,8 @@ hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
     static const int st_env = env_int("TTL_GEMM_BIG_STAGES", 0);
     static const int order_env = env_int("TTL_GEMM_BIG_ORDER", -1);
     static const int blocks_env = env_int("TTL_GEMM_BIG_BLOCKS", 0);
-    static std::atomic<int> ncu{0};
-    int cus = ncu.load();
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorInvalidDevice;
-        cus = p.multiProcessorCount; ncu.store(cus);
-    }
+    const int cus = device_cu_count();
+    if (!cus) return hipErrorInvalidDevice;
     int mt = mt_env;
     if ((size_t)((a.M + 32 * mt - 1) / (32 * mt)) * 32 * mt > (size_t)a.padded) mt = 5;   // a.padded = rows every output buffer has
     if ((size_t)((a.M + 159) / 160) * 160 > (size_t)a.padded) return hipErrorInvalidValue;
@@ -491,7 +503,12 @@ hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
     const int max_blocks = blocks_env ? blocks_env : cus;
     switch (epi) {
         case EPI_F32: return launch_big_v<EPI_F32>(a, mt, stages, order, max_blocks, s);
-        case EPI_OP: return launch_big_v<EPI_OP>(a, mt, stages, order, max_blocks, s);
+        case EPI_OP:
+            if (a.hm_T) {   // head-major q/k/v: N = 3*D with whole heads per 64 columns, row -> view by the checked multiplier
+                if (a.N % 192 || !a.hm_magic || a.hm_T < 1) return hipErrorInvalidValue;
+                return launch_big_v<EPI_OP_HM>(a, mt, stages, order, max_blocks, s);
+            }
+            return launch_big_v<EPI_OP>(a, mt, stages, order, max_blocks, s);
         case EPI_RESID_F32: return launch_big_v<EPI_RESID_F32>(a, mt, stages, order, max_blocks, s);
         case EPI_GELU: return a.C2 ? launch_big_v<EPI_GELU_C2>(a, mt, stages, order, max_blocks, s) : launch_big_v<EPI_GELU>(a, mt, stages, order, max_blocks, s);
         default: break;

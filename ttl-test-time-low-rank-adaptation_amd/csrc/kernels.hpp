@@ -1,7 +1,36 @@
 // Host-side launchers of the HIP kernels (one translation unit per kernel family).
 // All take a hipStream_t and enqueue only; none synchronises.
 #pragma once
+#include <atomic>
+
 #include "common.hpp"
+
+// ---------------------------------------------------------------- launch helpers (host)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `done` is the kernel's own bit mask of the
+// devices already served, so a second device used from the same process gets its opt-in too.  Thread-safe.
+inline hipError_t ensure_smem(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+// CU count of the CURRENT device (cached per device), 0 on error
+inline int device_cu_count() {
+    static std::atomic<int> ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int v = ncu[dev & 63].load(std::memory_order_relaxed);
+    if (v) return v;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    ncu[dev & 63].store(p.multiProcessorCount, std::memory_order_relaxed);
+    return p.multiProcessorCount;
+}
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 // C[M,N] (+)= A[M,K] * B[N,K]^T with bf16 operands (row-major, K contiguous), fp32 accumulate
@@ -33,11 +62,17 @@ struct GemmArgs {
     const int* amap;              // A operand rows
     const int* cmap;              // C and resid rows
     const int* c2map;             // C2 rows
+    // Head-major q/k/v output (EPI_OP on the big-M kernel only; hm_T == 0: plain row-major C).  Row m = view*hm_T + t, column
+    // c = plane*D + head*64 + d (D = N/3) goes to C[view*3*D*hm_T + plane*D*hm_T + head*64*hm_T + t*64 + d]: every (view, plane,
+    // head) is one contiguous [T][64] tile, which is what the attention kernels stage (QkvLayout below).  hm_magic: see qkv_hm_magic.
+    int hm_T; unsigned hm_magic;
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // gemm_big.hip: (32*MT) x 256 tiles, 8 waves, one persistent block per CU; big-M launches whose output buffers have
 // `a.padded` >= round_up(M, tile rows) rows (unguarded epilogue)
 bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a);
+// true iff launch_gemm(epi, a) runs on the big-M kernel (a.padded set as the caller will set it): the only path with GemmArgs::hm_T
+bool gemm_takes_big(GemmEpi epi, const GemmArgs& a);
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
@@ -82,19 +117,31 @@ hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, con
                                 const float* bias, float* out, int ldc, hipStream_t s, const int* cmap = nullptr);
 
 // ---------------------------------------------------------------- attention (attention.hip)
+// Where element d of (view n, token t, head h) of q / k / v sits in a q/k/v buffer (element offsets):
+//   q: n*view + t*tok + h*head + d,   k: + k_off,   v: + v_off
+// row-major [n*T][ld] (q | k | v along a row, the projection GEMM's natural output): 128-B head segments at a stride of ld;
+// head-major [n][3][H][T][64] (written by the big-M QKV GEMM's epilogue, GemmArgs::hm_T): contiguous [T][64] tiles.
+struct QkvLayout { long long view; int tok, head; long long k_off, v_off; };
+inline QkvLayout qkv_row_major(int T, int D, int ld) { return {(long long)T * ld, ld, 64, (long long)D, 2LL * D}; }
+inline QkvLayout qkv_head_major(int T, int H) {
+    const long long plane = (long long)H * 64 * T;
+    return {3 * plane, 64, 64 * T, plane, 2 * plane};
+}
+// m / T == __umulhi(m, magic) for every m < limit, or 0 when no such 32-bit multiplier exists (checked exhaustively)
+unsigned qkv_hm_magic(int T, int limit);
 // causal != 0: key j is visible to query i only for j <= i (text tower)
-hipError_t launch_attention_fwd(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T,
+hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout lay, op_t* out, int ld_out, float* lse, int n, int T,
                                 int H, hipStream_t s, int causal = 0);
-hipError_t launch_attention_bwd(const op_t* qkv, int ld_qkv, const op_t* out, const op_t* dout, int ld_o,
+hipError_t launch_attention_bwd(const op_t* qkv, QkvLayout lay, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s, int causal = 0);
 // Forward for query 0 of every sequence only (last image-tower layer): writes row n*T of `out` and lse[n][h][0].
-hipError_t launch_attention_fwd_cls(const op_t* qkv, int ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
+hipError_t launch_attention_fwd_cls(const op_t* qkv, QkvLayout lay, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                     hipStream_t s, const int* qpos = nullptr, int causal = 0);
 // Same gradients when d(out) is non-zero only for ONE query of every sequence (the top layer): token 0
 // (CLS) or, with qpos != null, token qpos[sequence] (end-of-text).  dout_cls bf16 [n][H*64]; writes dense
 // dq (zero rows for every other token), dk, dv.
-hipError_t launch_attention_bwd_cls(const op_t* qkv, int ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
+hipError_t launch_attention_bwd_cls(const op_t* qkv, QkvLayout lay, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s, const int* qpos = nullptr, int causal = 0);
 

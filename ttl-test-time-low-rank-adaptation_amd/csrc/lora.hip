@@ -206,12 +206,8 @@ template <int NCG, int KS>
 static hipError_t skinny_launch(const op_t* X, long long ldx, int3 xoff, int ntg, const op_t* W, int D, float scale, op_t* out,
                                 long long ldo, int M, hipStream_t s, const int* rowmap) {
     const int smem = 16 * NCG * (D * 2 + 16);
-    static std::atomic<bool> done{false};
-    if (!done.load()) {
-        hipError_t e = hipFuncSetAttribute((const void*)skinny_kernel<NCG, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        done.store(true);
-    }
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_smem((const void*)skinny_kernel<NCG, KS>, smem, done); e != hipSuccess) return e;
     hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 63) / 64, ntg), dim3(256), smem, s, X, ldx, xoff, W, D, scale, out, ldo, M, rowmap);
     return hipGetLastError();
 }
@@ -238,13 +234,13 @@ hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* par
     dim3 grid(nch, D / WG_BN, L.n);
     if (r == 16) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 16 * 2;
-        static std::atomic<bool> done{false};
-        if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
+        static std::atomic<uint64_t> done{0};
+        if (hipError_t e = ensure_smem((const void*)wgrad_kernel<16>, SMEM, done); e != hipSuccess) return e;
         hipLaunchKernelGGL((wgrad_kernel<16>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
     } else if (r == 32) {
         constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 32 * 2;
-        static std::atomic<bool> done{false};
-        if (!done.load()) { hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); if (e != hipSuccess) return e; done.store(true); }
+        static std::atomic<uint64_t> done{0};
+        if (hipError_t e = ensure_smem((const void*)wgrad_kernel<32>, SMEM, done); e != hipSuccess) return e;
         hipLaunchKernelGGL((wgrad_kernel<32>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
     } else return hipErrorInvalidValue;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);

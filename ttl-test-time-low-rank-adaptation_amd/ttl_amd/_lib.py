@@ -53,6 +53,7 @@ SIGNATURES = {
     "ttl_operand_dtype": (C.c_char_p, []),
     "ttl_workspace_bytes": (_Z, [C.POINTER(ttl_config)]),
     "ttl_ctx_create": (_I, [C.POINTER(ttl_config), C.POINTER(_P)]),
+    "ttl_ctx_create_shared": (_I, [C.POINTER(ttl_config), _P, C.POINTER(_P)]),
     "ttl_ctx_destroy": (None, [_P]),
     "ttl_load_weight": (_I, [_P, C.c_char_p, _P, _Z]),
     "ttl_load_weight_typed": (_I, [_P, C.c_char_p, _P, _Z, _I]),

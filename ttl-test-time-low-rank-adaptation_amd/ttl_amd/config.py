@@ -125,6 +125,13 @@ def ordered_targets(cfg):
     return tuple(t for t in LORA_TARGET_ORDER if t in cfg.lora_targets)
 
 
+def trainable_names(cfg, tower="vision_model"):
+    """State-dict names of the bound LoRA buffer's tensors, in its order (ttl.py:195-213: per layer q.A, q.B, v.A, v.B; with
+    k_proj / out_proj adapters configured: q, k, v, out)."""
+    return [f"{tower}.encoder.layers.{i}.self_attn.{pj}.lora_{ab}.default.weight"
+            for i in range(cfg.layer_lo, cfg.layer_hi + 1) for pj in ordered_targets(cfg) for ab in ("A", "B")]
+
+
 def targets_mask(cfg):
     return sum(LORA_TARGET_BITS[t] for t in ordered_targets(cfg))
 

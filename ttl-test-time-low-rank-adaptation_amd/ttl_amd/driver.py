@@ -138,12 +138,17 @@ class EpisodePipeline:
         from .engine import TTLEngine
         self.slots = []
         dev = torch.device(device)
+        # one copy of the frozen weights per GPU (the reference's single `model`, ttl.py:178-179): slots after the first read
+        # slot 0's images (ttl_ctx_create_shared).  TTL_SHARE_WEIGHTS=0: a private copy per slot (A/B, tools/ab_env.py).
+        share = os.environ.get("TTL_SHARE_WEIGHTS", "1") != "0"
         for _ in range(max(1, int(n_streams))):
             if engine_factory is not None:
                 eng = engine_factory()
             else:
-                eng = TTLEngine(cfg, max_views, text_features.shape[0], dev, precision)
-                eng.load_weights(weights)
+                owner = self.slots[0]["eng"] if (share and self.slots) else None
+                eng = TTLEngine(cfg, max_views, text_features.shape[0], dev, precision, share_from=owner)
+                if owner is None:
+                    eng.load_weights(weights)
                 eng.set_text_features(text_features, logit_scale_exp)
             flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in lora_names]).to(dev).contiguous()
             eng.bind_lora(flat)
@@ -230,5 +235,5 @@ class EpisodePipeline:
         return torch.stack([sl["acc"] for sl in self.slots]).sum(0)
 
     def close(self):
-        for sl in self.slots:
+        for sl in reversed(self.slots):          # the owner of the shared weight images (slot 0) goes last
             sl["eng"].close()

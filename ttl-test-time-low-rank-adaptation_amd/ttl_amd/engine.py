@@ -31,8 +31,11 @@ def _stream():
 class TTLEngine:
     """Owns the HIP context (frozen bf16 weights + activation arena) of one image tower."""
 
-    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device, precision: str = "bf16"):
-        """precision: MFMA operand dtype — "bf16" (default) or "fp16" (the reference's autocast dtype)."""
+    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device, precision: str = "bf16", share_from=None):
+        """precision: MFMA operand dtype — "bf16" (default) or "fp16" (the reference's autocast dtype).
+        share_from: an engine of the same model whose weights are loaded — this engine then reads that engine's frozen
+        weight images instead of holding copies (ttl_ctx_create_shared; the reference has ONE model per process,
+        ttl.py:178-179); ``load_weights`` must not be called on it and ``share_from`` must stay open while it is in use."""
         self.precision = precision
         self.lib = _lib.load(precision)
         self.cfg = cfg
@@ -45,8 +48,14 @@ class TTLEngine:
         c = self._make_config(cfg)
         self._ccfg = c
         h = C.c_void_p()
+        self._parent = share_from                      # keeps the owner of the shared images alive
         with torch.cuda.device(self.device):
-            self._check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
+            if share_from is not None:
+                if share_from.precision != precision or share_from.device != self.device:
+                    raise _lib.TtlError("share_from must be an engine of the same build on the same device")
+                self._check(self.lib.ttl_ctx_create_shared(C.byref(c), share_from._h, C.byref(h)))
+            else:
+                self._check(self.lib.ttl_ctx_create(C.byref(c), C.byref(h)))
         self._h = h
         from .config import ordered_targets
         self.n_lora = (cfg.layer_hi - cfg.layer_lo + 1) * len(ordered_targets(cfg)) * 2 * cfg.rank * cfg.width
