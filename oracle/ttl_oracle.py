@@ -220,6 +220,9 @@ class VitOracle:
     def __init__(self, cfg, W, lora, prec="fp32"):
         self.cfg, self.W, self.lora, self.prec = cfg, W, lora, prec
         self.r = _rounder(prec)
+        # rounding points of the BACKWARD by name ("dh", "du", "dhm", "do", "P", "dS", "dqkv", "dU", "w"): a diagnostic
+        # (tools/fp16_grad_points.py) replaces this hook to switch single points on and off; default: the build's rounder
+        self.rb = lambda name, x: self.r(x)
 
     # -- parameter access
     def _lw(self, i, name):
@@ -345,7 +348,8 @@ class VitOracle:
 
     def backward_layers(self, dh, save):
         """d/d(residual stream after the last layer) [N,T,D] -> LoRA grads of the trained layers."""
-        c, r = self.cfg, self.r
+        c, rb = self.cfg, self.rb
+        r = lambda w: rb("w", w)                     # frozen weights / adapters as operands
         N = dh.shape[0]
         T, D, Hh, dhd = c.tokens, c.width, c.heads, c.head_dim
         s = np.float32(c.scaling)
@@ -356,22 +360,22 @@ class VitOracle:
             sv = save[i]
             first = (i == c.layer_lo)
             # MLP
-            dg = r(dh) @ r(self._lw(i, "mlp.fc2.weight"))
-            du = r((dg * quick_gelu_grad(sv["u"])).astype(np.float32))
+            dg = rb("dh", dh) @ r(self._lw(i, "mlp.fc2.weight"))
+            du = rb("du", (dg * quick_gelu_grad(sv["u"])).astype(np.float32))
             dx2 = du @ r(self._lw(i, "mlp.fc1.weight"))
             dhm = dh + layer_norm_bwd(dx2, sv["h_mid"], sv["mu2"], sv["rs2"], self._lw(i, "layer_norm2.weight"))
             # attention
             base = f"{self.tower}.encoder.layers.{i}.self_attn."
             tg = self.targets(i)
-            do = r(dhm) @ r(self._lw(i, "self_attn.out_proj.weight"))
+            do = rb("dhm", dhm) @ r(self._lw(i, "self_attn.out_proj.weight"))
             if "out_proj" in tg:
                 Ao, Bo = self._lora(i, "out_proj", "A"), self._lora(i, "out_proj", "B")
-                dhm16 = r(dhm).reshape(N * T, D)
-                dUo = r(s * (dhm16 @ r(Bo)))
+                dhm16 = rb("dhm", dhm).reshape(N * T, D)
+                dUo = rb("dU", s * (dhm16 @ r(Bo)))
                 do = do + (dUo @ r(Ao)).reshape(N, T, D)
                 grads[base + "out_proj.lora_B.default.weight"] = (dhm16.T @ sv["U"]["out_proj"].reshape(N * T, -1)).astype(np.float32)
                 grads[base + "out_proj.lora_A.default.weight"] = (dUo.T @ sv["o"].reshape(N * T, D)).astype(np.float32)
-            do = r(do.astype(np.float32))
+            do = rb("do", do.astype(np.float32))
             dO = do.reshape(N, T, Hh, dhd).transpose(0, 2, 1, 3)
             q, k, v = sv["q"], sv["k"], sv["v"]
             sc = (q @ k.transpose(0, 1, 3, 2)) * np.float32(dhd ** -0.5)
@@ -380,11 +384,11 @@ class VitOracle:
             Pm = np.exp(sc - sv["lse"][..., None])
             O = sv["o"].reshape(N, T, Hh, dhd).transpose(0, 2, 1, 3)
             delta = (dO * O).sum(-1, keepdims=True)
-            dV = r(Pm).transpose(0, 1, 3, 2) @ dO
+            dV = rb("P", Pm).transpose(0, 1, 3, 2) @ dO
             dP = dO @ v.transpose(0, 1, 3, 2)
-            dS = r((Pm * (dP - delta)).astype(np.float32))
+            dS = rb("dS", (Pm * (dP - delta)).astype(np.float32))
             dQ = (dS @ k) * np.float32(dhd ** -0.5)
-            merge = lambda a: r(a.transpose(0, 2, 1, 3).reshape(N * T, D).astype(np.float32))
+            merge = lambda a: rb("dqkv", a.transpose(0, 2, 1, 3).reshape(N * T, D).astype(np.float32))
             dq, dv = merge(dQ), merge(dV)
             x1 = sv["x1"].reshape(N * T, D)
             dk = None
@@ -398,7 +402,7 @@ class VitOracle:
                 A, B = self._lora(i, pj, "A"), self._lora(i, pj, "B")
                 Us = sv["U"][pj].reshape(N * T, -1)            # = s·x1·A^T
                 grads[base + pj + ".lora_B.default.weight"] = (dproj.T @ Us).astype(np.float32)
-                dU[pj] = r(s * (dproj @ r(B)))                 # [M,r]
+                dU[pj] = rb("dU", s * (dproj @ r(B)))                 # [M,r]
                 grads[base + pj + ".lora_A.default.weight"] = (dU[pj].T @ x1).astype(np.float32)
             if first:
                 break

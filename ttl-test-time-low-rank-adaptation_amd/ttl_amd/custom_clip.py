@@ -131,11 +131,11 @@ class _TextModeEngine:
         """Logits of other views against the text features of the LAST forward, without touching the text context
         (whose saved activations and image features belong to a pending backward): the PLPD forward of deyo.py:135.
         The adapters have not changed in between, so the reference's recomputed text features are the same ones.
-        A [n,E] x [E,K] product in torch: host-side glue, like the reference's own softmax / gather around it."""
-        f = self.img.features(x)
-        f = f / f.norm(dim=-1, keepdim=True)
+        The product itself (deyo.py:135-136 -> clip/custom_clip.py:679-687) is the HIP logit head of the IMAGE context
+        (ttl_head_logits), whose class embeddings are set to those text features first."""
         t = self._last_text / self._last_text.norm(dim=-1, keepdim=True)
-        return self.txt._scale * f @ t.t()
+        self.img.set_text_features(t, self.txt._scale)
+        return self.img.head_logits(self.img.features(x))
 
     def backward(self, dlogits):
         return self.txt.backward(dlogits)
@@ -183,7 +183,7 @@ class _PlpdTextForward:
 def build_text_mode_engine(vcfg, tcfg, vision_state, text_state, prompts, logit_scale_exp, device, max_views, max_prompts,
                            precision="bf16"):
     """Image context (no adapters) + text-tower context with prompts and logit scale set; LoRA still unbound."""
-    img = TTLEngine(vcfg, max_views, 1, device, precision)
+    img = TTLEngine(vcfg, max_views, max_prompts, device, precision)      # (class capacity: the PLPD forward scores views on it)
     img.load_weights(vision_state)
     txt = TextTowerEngine(tcfg, max_prompts, max_views, device, precision)
     txt.load_weights(text_state)

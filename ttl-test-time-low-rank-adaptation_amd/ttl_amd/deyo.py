@@ -114,7 +114,7 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     # the torch scaler object only supplies its hyper-parameters, see TTLEngine.bind_scaler)
     eng.optimizer_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd, n_selected=L["n"])
     n = int(L["n"].item())                                                       # the host sync of the step
-    if n and eng.scaler_state()["optimizer_steps"] == step + 1:                  # taken (not skipped on inf/nan)
+    if n and _scaled_engine(eng).step_was_taken():                               # taken (not skipped on inf/nan)
         for p in params:
             optimizer.state[p]["step"] += 1
     return outputs, (n if backward is None else backward), n

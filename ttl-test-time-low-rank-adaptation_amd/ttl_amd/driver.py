@@ -17,6 +17,107 @@ def dist_env():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys", env=None):
+    """(numa node, set of CPUs) of the NUMA node the ``local_rank``-th VISIBLE GPU hangs off, read from sysfs without touching
+    the GPU: KFD topology nodes with simd_count > 0 are the GPUs in the runtime's enumeration order, HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES select and reorder them, the node's drm_render_minor leads to .../device/numa_node.
+    (None, None) when any of it cannot be read (containers without /sys/class/kfd, numa_node == -1)."""
+    env = os.environ if env is None else env
+    try:
+        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split()[:2] for l in open(os.path.join(base, n, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", 0)) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            gpus = [gpus[int(v)] for v in vis.split(",") if v.strip().isdigit() and int(v) < len(gpus)]
+        minor = gpus[local_rank]
+        node = int(open(os.path.join(sysfs, f"class/drm/renderD{minor}/device/numa_node")).read())
+        if node < 0:
+            return None, None
+        return node, _parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read())
+    except (OSError, ValueError, IndexError, KeyError):
+        return None, None
+
+
+def pin_to_gpu_numa_node(local_rank, n_local_ranks=1, sysfs="/sys", env=None, apply=True):
+    """Restrict this process (call it BEFORE torch / HIP start their threads and before any GPU call) to the CPUs of its GPU's
+    NUMA node, so the episode's ~130 kernel enqueues per image and the allocator's host threads stay next to the device's PCIe
+    root.  Several ranks on one node share its CPUs (the scheduler spreads them).  Returns a small record for the bench line;
+    never raises: an unreadable topology leaves the affinity alone."""
+    node, cpus = gpu_numa_cpus(local_rank, sysfs, env)
+    rec = {"local_rank": int(local_rank), "numa_node": node, "applied": False}
+    if node is None:
+        rec["reason"] = "GPU -> NUMA node not readable from sysfs"
+        return rec
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:          # pragma: no cover
+        rec["reason"] = "no sched_getaffinity on this platform"
+        return rec
+    target = cpus & allowed
+    if len(target) < 2:
+        rec["reason"] = f"only {len(target)} of the node's CPUs are allowed for this process"
+        return rec
+    rec["cpus"] = len(target)
+    if apply:
+        os.sched_setaffinity(0, target)
+        rec["applied"] = True
+    return rec
+
+
+class ShardProgress:
+    """Per-rank progress file of a sharded evaluation: {tag, rank, world, next_index, acc}.  The reference's loop
+    (ttl.py:321-356) keeps its AverageMeters in memory only — a 50k-image run that dies starts over.  Test images are
+    independent episodes and the view RNG is keyed by (seed, global index), so a rank can pick up at the first index it has
+    not accounted for: ``resume()`` -> (first index to run, accumulator so far); ``note(i, totals_fn)`` after item i has been
+    submitted — every ``every`` owned items the accumulator is fetched (that drains the streams) and the file replaced
+    atomically.  A file written for another tag / rank / world size is ignored."""
+
+    def __init__(self, path, rank, world, tag="", every=256):
+        self.path = f"{path}.rank{int(rank)}of{int(world)}.json"
+        self.key = dict(tag=str(tag), rank=int(rank), world=int(world))
+        self.every, self._since = max(int(every), 1), 0
+
+    def resume(self):
+        import json
+        try:
+            with open(self.path) as f:
+                d = json.load(f)
+            if all(d.get(k) == v for k, v in self.key.items()):
+                return int(d["next_index"]), [int(v) for v in d["acc"]]
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+        return 0, [0, 0, 0]
+
+    def write(self, next_index, acc):
+        import json
+        tmp = self.path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(dict(self.key, next_index=int(next_index), acc=[int(v) for v in acc]), f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, self.path)
+
+    def note(self, i, totals_fn):
+        self._since += 1
+        if self._since >= self.every:
+            self._since = 0
+            self.write(i + 1, totals_fn())
+
+
 def shard_indices(n_items, rank, world):
     """Strided partition: invariant per-index work assignment, balanced to within one item."""
     return range(rank, n_items, world)
@@ -80,18 +181,29 @@ def topk_hits(logits, target, ks=(1, 5)):
     return [eq[:, :min(kk, k)].any(dim=1).sum() for kk in ks]
 
 
-def evaluate_sharded(predict_fn, n_items, label_fn, rank=0, world=1, device="cpu", group=None):
+def evaluate_sharded(predict_fn, n_items, label_fn, rank=0, world=1, device="cpu", group=None, progress=None):
     """predict_fn(i) -> logits [1,K] after adaptation on test item i; label_fn(i) -> int.
+    ``progress``: a ShardProgress — items this rank has already accounted for are skipped and its saved accumulator continues.
     Returns dict(top1, top5, count, hits1, hits5) — identical on every rank."""
     shard = ImageShard(rank, world, group)
     acc = torch.zeros(3, dtype=torch.int64, device=device)      # [hits1, hits5, count]
+    start = 0
+    if progress is not None:
+        start, acc0 = progress.resume()
+        acc += torch.tensor(acc0, dtype=torch.int64, device=device)
     for i in shard.indices(n_items):
+        if i < start:
+            continue
         logits = predict_fn(i)
         tgt = torch.tensor([label_fn(i)], device=logits.device)
         h1, h5 = topk_hits(logits, tgt)
         acc[0] += h1.to(acc.device)
         acc[1] += h5.to(acc.device)
         acc[2] += 1
+        if progress is not None:
+            progress.note(i, lambda: acc.tolist())
+    if progress is not None:
+        progress.write(n_items, acc.tolist())
     return shard.accuracy(acc)
 
 

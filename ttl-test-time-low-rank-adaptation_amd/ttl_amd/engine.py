@@ -227,10 +227,21 @@ class TTLEngine:
 
     def optimizer_step(self, params, grads, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, n_selected=None):
         """scaler.step(optimizer) + scaler.update(): AdamW over the flat buffer — the whole step or none of it."""
+        if getattr(self, "_skipped_seen", None) is None:     # baseline for step_was_taken(): skips recorded before this step
+            self._skipped_seen = self.scaler_state()["skipped_steps"]
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_optimizer_step(self._h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
                                                     betas[1], eps, weight_decay, int(step),
                                                     _ptr(n_selected) if n_selected is not None else None, _stream()))
+
+    def step_was_taken(self):
+        """After ``optimizer_step``: did the scaler apply the update (True) or skip the whole step on inf/nan gradients?
+        Decided from the context's count of skipped steps before and after the call — the device's step counter is reset by
+        ttl_episode* only, so on the step-wise path it can still hold the previous image's value.  One host sync."""
+        seen = self.scaler_state()["skipped_steps"]
+        taken = seen == self._skipped_seen
+        self._skipped_seen = seen
+        return taken
 
     def lora_reset(self, params, snapshot, m=None, v=None):
         with torch.cuda.device(self.device):
@@ -241,6 +252,7 @@ class TTLEngine:
                 want_logits0=False):
         """One whole test image (ttl.py:338-352) as a single enqueue; returns logits1 [1,K] (and logits0)."""
         import math
+        self._skipped_seen = None            # a fused episode may skip steps of its own: step_was_taken() re-reads its baseline
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         n = x.shape[0]
         l1 = torch.empty((1, self.n_classes), dtype=torch.float32, device=self.device)
@@ -374,6 +386,7 @@ class TextTowerEngine(TTLEngine):
                 eps=1e-8, weight_decay=1e-2, want_logits0=False):
         """Whole text-mode episode as one enqueue; ``image_engine`` is an adapter-less image-tower engine."""
         import math
+        self._skipped_seen = None
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         n = x.shape[0]
         l1 = torch.empty((1, self.n_prompts), dtype=torch.float32, device=self.device)

@@ -38,13 +38,15 @@ def episode_kwargs_from_args(args):
 
 
 def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state, scaler, args, n_streams=3,
-                         rank=0, world=1, gpu_augmenter=None):
+                         rank=0, world=1, gpu_augmenter=None, progress=None):
     """Same call shape as ttl.py:300.  ``val_loader`` yields (images, target) with images either a
     list of [1,3,S,S] tensors (view 0 first, like AugMixAugmenter) or one [N,3,S,S] tensor — or, with
     ``gpu_augmenter`` (views.GpuAugMixAugmenter), one decoded uint8 [H,W,3] image whose views are then
     generated on the GPU (bit-exact with the host Pillow pipeline for the same crop boxes).
     ``optimizer`` supplies the AdamW hyper-parameters; ``model_state``/``optim_state``/``scaler`` are
     accepted for signature compatibility (the fused episode resets LoRA and Adam state itself).
+    ``progress`` (driver.ShardProgress): per-rank resume file — items this rank has accounted for are skipped and its saved
+    [hits1, hits5, count] continues (a sharded 50k-image run that dies does not start over).
     Returns [top1, top5] in percent, identical on every rank."""
     from .deyo import _adam_hparams
     model.eval()
@@ -86,8 +88,12 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
                                             precision=model.precision, engine_factory=factory, n_classes=n_cls)
     dev = eng.device
     shard = ImageShard(rank, world)
+    start, acc0 = (0, [0, 0, 0]) if progress is None else progress.resume()
+    acc0 = torch.tensor(acc0, dtype=torch.int64, device=dev)
+    n_seen = 0
     for i, (images, target) in enumerate(val_loader):
-        if not shard.owns(i):
+        n_seen = i + 1
+        if not shard.owns(i) or i < start:
             continue
         if gpu_augmenter is not None and torch.is_tensor(images) and images.dtype == torch.uint8:
             images = gpu_augmenter(images.to(dev, non_blocking=True), i)                    # datautils.py:141-157 on the GPU
@@ -99,7 +105,12 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
                 images = images.squeeze(0)
         tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev)
         pipe.submit(images, target=tgt, **kw)
-    r = shard.accuracy(pipe.totals())
+        if progress is not None:
+            progress.note(i, lambda: (pipe.totals() + acc0).tolist())
+    totals = pipe.totals() + acc0
+    if progress is not None:
+        progress.write(n_seen, totals.tolist())
+    r = shard.accuracy(totals)
     return [r["top1"], r["top5"]]
 
 
@@ -201,8 +212,12 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
+    ap.add_argument("--resume_file", default=None, help="prefix of the per-rank progress files (driver.ShardProgress): a run that "
+                    "is started again with the same arguments continues after the last recorded image of every rank")
     a = ap.parse_args()
     rank, local, world = dist_env()
+    from .driver import ShardProgress, pin_to_gpu_numa_node
+    pin_to_gpu_numa_node(local, world)          # before the first GPU call: host threads next to the device's PCIe root
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -225,7 +240,10 @@ def main():
                          world=world, gpu_augmenter=aug)
     torch.cuda.synchronize()
     t0 = time.time()
-    top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world,
+    progress = None
+    if a.resume_file:
+        progress = ShardProgress(a.resume_file, rank, world, tag=f"{a.arch}|{a.images}|{a.views}|{a.classes}|{a.rank}|{a.lora_encoder}|{a.gpu_views}")
+    top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world, progress=progress,
                                       gpu_augmenter=aug)
     dt = time.time() - t0
     if rank == 0:

@@ -54,7 +54,7 @@ def test_time_tuning(model, inputs, optimizer, scaler, args):
         for p, g in zip(params, _grad_views(eng, params)):
             p.grad = g
         eng.optimizer_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd)   # ttl.py:106-108
-        if eng.scaler_state()["optimizer_steps"] == step + 1:       # taken (GradScaler skips the whole step on inf/nan)
+        if _deyo._scaled_engine(eng).step_was_taken():               # taken (GradScaler skips the whole step on inf/nan)
             for p in params:
                 optimizer.state[p]["step"] += 1
     return
