@@ -108,12 +108,13 @@ def non_gemm_flops_executed(cfg, n_views, n_classes):
 def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
     """The path on the host cores, as SURVEY.md §8(d) specifies it: torch fp32 (oracle/ttl_oracle_torch.py: torch matmuls,
     autograd, torch.optim.AdamW — the reference's own CPU software stack, restated because /root/reference cannot travel; pinned
-    to the reference-generated fixtures by tests/test_oracle_golden.py), one thread per PHYSICAL core, the FULL view count,
+    to the reference-generated fixtures by tests/test_oracle_golden.py), one thread per PHYSICAL core the container may use
+    (the GPU boxes show 256 logical CPUs behind a cgroup quota of 16: 128 threads there run 2x SLOWER than 16), the FULL view count,
     3 warm-up episodes + as many timed ones as fit the budget (>= 5, at most 10).  A reported baseline, never the target."""
     import torch
     from oracle import ttl_oracle_torch as OT
     from ttl_amd import synth
-    cores = OT.physical_cores()
+    cores = OT.usable_cores()             # physical cores, capped by the container's CPU quota (more threads are throttled)
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     try:
@@ -141,8 +142,8 @@ def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
     except Exception:
         pass
     out = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-           "logical_cpus": os.cpu_count(),
-           "sample": f"oracle/ttl_oracle_torch.py (torch {torch.__version__} fp32, autograd + AdamW, {cores} threads = physical cores): "
+           "logical_cpus": os.cpu_count(), "physical_cores": OT.physical_cores(), "cgroup_cpu_quota": OT.cgroup_cpu_quota(),
+           "sample": f"oracle/ttl_oracle_torch.py (torch {torch.__version__} fp32, autograd + AdamW, {cores} threads = physical cores the container's CPU quota allows): "
                      f"3 warm-up + {len(times)} timed episodes on {full_views} of {full_views} views, K={n_classes}, median {dt:.2f} s "
                      f"(min {min(times):.2f}, max {max(times):.2f}; warm-up {t_warm[0]:.2f} / {t_warm[-1]:.2f}); class-text features "
                      f"cached like the GPU path"}
@@ -212,10 +213,16 @@ def parity_check(precision):
            "lora_weights_frac_beyond_tolerance": round(wfar / max(wn, 1), 6),
            "mask_exact": mask, "top1_equal": bool(int(l1.argmax()) == int(g["top5"][0, 0])),
            "north_star_tolerance": tol,
-           # BASELINE.json north_star: selection mask bit-exact, logits and LoRA weights within 1e-3.  The post-step weights are
-           # a sign-like function of the gradient (first AdamW step, Q11: +-lr whatever |g| is), so "weights within 1e-3" is
-           # judged on the gradients that produce them; the fraction of weight elements beyond 1e-3 is reported beside it.
-           "meets_north_star_tolerance": bool(mask and le <= tol and ae <= tol and gerr <= tol)}
+           # BASELINE.json north_star, item by item: selection mask bit-exact, logits within 1e-3, LoRA weights within 1e-3.
+           # The post-step weights are a SIGN-like function of the gradient (first AdamW step from zero state, Q11:
+           # -lr*g/(|g|+eps)), so an element whose gradient is smaller than the gradient deviation lands 2*lr away whatever
+           # the implementation; the gradient deviation itself is set by the 16-bit FORWARD (an exact fp32 backward after the
+           # same fp16 forward sits at 2.9e-3 on this fixture: profiles/r03_fp16_grad_points.txt), i.e. it is a property of
+           # 16-bit operands — the reference's own autocast path included — not of this backward.
+           "meets_north_star_tolerance": {"selection_mask": mask, "logits": bool(le <= tol and ae <= tol),
+                                          "lora_weights": bool(werr <= tol * max(float(np.abs(g["lora1/" + k]).max()) for k in names)),
+                                          "lora_gradients": bool(gerr <= tol),
+                                          "all": bool(mask and le <= tol and ae <= tol and gerr <= tol)}}
     eng.close()
     return out
 

@@ -103,6 +103,10 @@ int main(int argc, char** argv) {
     if (!o || fwrite(out, 4, (size_t)nv * nk + nk, o) != (size_t)nv * nk + nk) return 1;
     fclose(o);
     p_ttl_ctx_destroy(ctx);
+    CHECK_HIP(hipStreamDestroy(s));
+    CHECK_HIP(hipFree(d_x)); CHECK_HIP(hipFree(d_lora)); CHECK_HIP(hipFree(d_grad)); CHECK_HIP(hipFree(d_snap));
+    CHECK_HIP(hipFree(d_m)); CHECK_HIP(hipFree(d_v)); CHECK_HIP(hipFree(d_logits)); CHECK_HIP(hipFree(d_l1));
+    free(out); free(tf); free(lora); free(x);
     printf("standalone ok: %d views, %d classes\n", nv, nk);
     return 0;
 }

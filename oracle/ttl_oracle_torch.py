@@ -44,6 +44,28 @@ def physical_cores():
     return max(len(cores), 1)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable.
+    More threads than this are throttled, not run: on the GPU boxes 256 logical CPUs are visible behind a quota of 16."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(int(int(q) / int(p)), 1)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(int(q / p), 1)
+    except (OSError, ValueError):
+        return None
+
+
+def usable_cores():
+    """Threads worth starting: the physical cores this process may run on, capped by the container's CPU quota."""
+    q = cgroup_cpu_quota()
+    return min(physical_cores(), q) if q else physical_cores()
+
+
 class TorchTower:
     """Frozen CLIP ViT weights as torch tensors (converted once; the timed episodes only compute)."""
 

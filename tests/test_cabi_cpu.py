@@ -5,6 +5,7 @@ import os
 
 import pytest
 
+from conftest import ROOT
 from ttl_amd import _lib
 
 
@@ -102,3 +103,28 @@ def test_struct_layouts_match_the_header_and_the_documented_stub(tmp_path):
     n_init = len(re.search(r"cfg = ttl_config\((.*?)\)", doc).group(1).split(","))
     assert n_init == len(c_fields("ttl_config"))
 
+
+
+def test_big_gemm_epilogues_issue_the_stores_the_counted_waits_allow_for():
+    """gemm_big.hip's first waits of a block's next tile allow for 4*MT unacknowledged epilogue stores per wave
+    (wait_tiles1_st); fewer store instructions in some epilogue would let a K-tile be read before it lands.  Checked on the
+    ISA hipcc really emits for gfx950 (tools/check_big_epilogue.py)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_big_epilogue.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "gemm_big_kernel<5,3,2>: 20 store" in r.stdout
+
+
+def test_degenerate_configs_are_refused_not_crashed():
+    """Config validation runs before anything touches a device: an all-zero ttl_config (heads == 0 used to divide by zero —
+    found by the ASan host test) and other degenerate fields come back as TTL_EINVAL with a message."""
+    lib = _lib.load("bf16")
+    h = C.c_void_p()
+    cfg = _lib.ttl_config()
+    assert lib.ttl_ctx_create(C.byref(cfg), C.byref(h)) != 0 and not h.value
+    assert b"positive" in lib.ttl_last_error()
+    assert lib.ttl_workspace_bytes(C.byref(cfg)) == 0
+    cfg = _lib.ttl_config(224, 0, 768, 12, 3072, 12, 512, 16, 32.0, 9, 11, 1e-5, 64, 200, 0, 0, 0, 0)     # patch_size 0
+    assert lib.ttl_ctx_create(C.byref(cfg), C.byref(h)) != 0 and not h.value
+    cfg = _lib.ttl_config(8, 16, 768, 12, 3072, 12, 512, 16, 32.0, 9, 11, 1e-5, 64, 200, 0, 0, 0, 0)       # image smaller than a patch
+    assert lib.ttl_ctx_create(C.byref(cfg), C.byref(h)) != 0 and not h.value

@@ -21,6 +21,25 @@ def build(tmp_path):
     return exe
 
 
+def write_bundle(tmp_path, cfg, W, tf, scale, flat, x):
+    """the example's input file: geometry, every tensor by name, class features, logit scale, adapters, views"""
+    N, K = x.shape[0], tf.shape[0]
+    bundle = tmp_path / "bundle.bin"
+    with open(bundle, "wb") as f:
+        f.write(struct.pack("<8i", cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers, cfg.embed, cfg.rank))
+        f.write(struct.pack("<f2if2i", cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps, N, K))
+        tensors = {k: v for k, v in W.items() if k != "logit_scale"}
+        f.write(struct.pack("<3i", N, K, len(tensors)))
+        for k, v in tensors.items():
+            a = np.ascontiguousarray(v, np.float32)
+            f.write(struct.pack("<i", len(k)) + k.encode() + struct.pack("<q", a.size) + a.tobytes())
+        f.write(np.ascontiguousarray(tf, np.float32).tobytes())
+        f.write(struct.pack("<f", scale))
+        f.write(flat.tobytes())
+        f.write(np.ascontiguousarray(x, np.float32).tobytes())
+    return bundle
+
+
 def test_header_and_example_compile_as_plain_c(tmp_path):
     assert os.path.exists(build(tmp_path))
 
@@ -37,19 +56,7 @@ def test_standalone_c_host_matches_python_engine(tmp_path):
     names = O.trainable_names(cfg)
     flat = np.concatenate([lora0[k].reshape(-1) for k in names]).astype(np.float32)
     scale = float(np.exp(W["logit_scale"]))
-    bundle = tmp_path / "bundle.bin"
-    with open(bundle, "wb") as f:
-        f.write(struct.pack("<8i", cfg.image_size, cfg.patch_size, cfg.width, cfg.heads, cfg.mlp, cfg.layers, cfg.embed, cfg.rank))
-        f.write(struct.pack("<f2if2i", cfg.lora_alpha, cfg.layer_lo, cfg.layer_hi, cfg.ln_eps, N, K))
-        tensors = {k: v for k, v in W.items() if k != "logit_scale"}
-        f.write(struct.pack("<3i", N, K, len(tensors)))
-        for k, v in tensors.items():
-            a = np.ascontiguousarray(v, np.float32)
-            f.write(struct.pack("<i", len(k)) + k.encode() + struct.pack("<q", a.size) + a.tobytes())
-        f.write(np.ascontiguousarray(tf, np.float32).tobytes())
-        f.write(struct.pack("<f", scale))
-        f.write(flat.tobytes())
-        f.write(np.ascontiguousarray(x, np.float32).tobytes())
+    bundle = write_bundle(tmp_path, cfg, W, tf, scale, flat, x)
     exe = build(tmp_path)
     out = tmp_path / "out.bin"
     r = subprocess.run([exe, _lib.LIB_PATHS["bf16"], str(bundle), str(out)], capture_output=True, text=True, timeout=300)

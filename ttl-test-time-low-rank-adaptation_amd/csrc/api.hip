@@ -152,6 +152,8 @@ int dalloc(ttl_ctx* c, Tp** p, size_t count, bool zero = false) {
 
 int check_config(const ttl_config* k) {
     if (!k) return fail(TTL_EINVAL, "null config");
+    if (k->width < 128 || k->heads < 1 || k->mlp < 128 || k->layers < 1)      // (before any division by them)
+        return fail(TTL_EINVAL, "width / heads / mlp / layers must be positive (got D=%d H=%d F=%d L=%d)", k->width, k->heads, k->mlp, k->layers);
     if (k->width % 128 || k->width / k->heads != 64 || k->width % k->heads)
         return fail(TTL_EINVAL, "width must be a multiple of 128 with head_dim 64 (got D=%d H=%d)", k->width, k->heads);
     if (k->mlp % 128) return fail(TTL_EINVAL, "mlp must be a multiple of 128");
@@ -160,7 +162,8 @@ int check_config(const ttl_config* k) {
     if (k->tower == TTL_TOWER_TEXT) {
         if (k->context_length < 2 || k->context_length > 128 || k->vocab_size < 2)
             return fail(TTL_EINVAL, "bad context_length %d / vocab_size %d", k->context_length, k->vocab_size);
-    } else if (k->patch_size < 1 || k->image_size % k->patch_size || k->image_size % 8) return fail(TTL_EINVAL, "bad image/patch size");
+    } else if (k->patch_size < 1 || k->image_size < k->patch_size || k->image_size % k->patch_size || k->image_size % 8)
+        return fail(TTL_EINVAL, "bad image/patch size");
     if (k->layer_lo < 0 || k->layer_hi >= k->layers || k->layer_lo > k->layer_hi)
         return fail(TTL_EINVAL, "bad layer range [%d,%d] for %d layers", k->layer_lo, k->layer_hi, k->layers);
     int T = k->tower == TTL_TOWER_TEXT ? k->context_length : (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;

@@ -22,6 +22,7 @@ typedef __bf16 op_scalar;
 #define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
 #define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
 #endif
+#ifndef TTL_HOST_STUB   // (`make asan`: the host glue compiled as plain C++ against asan/hip/hip_runtime.h needs the storage type only)
 typedef __attribute__((ext_vector_type(8))) op_scalar opx8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -83,3 +84,4 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
 }
+#endif  // TTL_HOST_STUB
