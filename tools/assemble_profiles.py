@@ -22,7 +22,9 @@ def last_json(path):
 
 def short(d):
     r = d["roofline"]
-    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "config": d["config"]["workload"],
+    return {"value": d["value"], "value_min": d.get("value_min"), "value_max": d.get("value_max"), "unit": d["unit"],
+            "ms_per_step": d["ms_per_step"], "host_enqueue_ms_per_image": d.get("host_enqueue_ms_per_image"),
+            "hip_graph": d["config"].get("hip_graph"), "config": d["config"]["workload"],
             "gemm_tflops_alone": r["achieved"], "gemm_frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
             "whole_path_frac_of_bf16_peak": d.get("whole_path_frac_of_bf16_peak"),
             "whole_path_frac_executed": d.get("whole_path_frac_executed")}
@@ -34,15 +36,16 @@ def main(src, tag):
     b = last_json(f"{src}/bench.json")
     if b:
         json.dump(b, open(f"{out}/{tag}_bench.json", "w"), indent=1)
-    for sub, name in (("prof3/p3_kernel_stats.csv", "bench_default_3streams_kernel_stats.csv"),
-                      ("prof1/p1_kernel_stats.csv", "bench_streams1_kernel_stats.csv")):
+    # ONE kernel-stats file: rocprofv3 serialises kernels, so the regime is "kernel alone on the chip" whatever --streams was
+    for sub, name in (("prof1/p1_kernel_stats.csv", "bench_kernel_stats_serialized.csv"),):
         cand = [os.path.join(dp, f) for dp, _, fs in os.walk(f"{src}/{sub.split('/')[0]}") for f in fs if f.endswith("kernel_stats.csv")]
         if cand:
             shutil.copy(cand[0], f"{out}/{tag}_{name}")
     if os.path.exists(f"{src}/prof1_gemm_shapes.txt"):
-        shutil.copy(f"{src}/prof1_gemm_shapes.txt", f"{out}/{tag}_gemm_shapes_streams1.txt")
+        shutil.copy(f"{src}/prof1_gemm_shapes.txt", f"{out}/{tag}_gemm_shapes_serialized.txt")
     other = {}
-    for key, f in (("streams1", "bench_streams1.json"), ("k1000", "bench_k1000.json"), ("vit_l14", "bench_l14.json"),
+    for key, f in (("streams1", "bench_streams1.json"), ("adapters_q_k_v_out", "bench_qkvo.json"), ("plain_enqueues_no_graph", "bench_graph0.json"),
+                   ("fp16_operands_as_the_benched_build", "bench_fp16.json"), ("k1000", "bench_k1000.json"), ("vit_l14", "bench_l14.json"),
                    ("r32_128v_4updates", "bench_r32_128v_4up.json"), ("r32_128v_16updates", "bench_r32_128v_16up.json"),
                    ("8views_k10_hip_graph", "bench_8v_graph.json")):
         d = last_json(f"{src}/{f}")
@@ -82,7 +85,7 @@ def main(src, tag):
             k["views_kernel+coef_kernel"] = {"what": "64 views of one 375x500 uint8 image: write fp32 [64,3,224,224] (38.5 MB), source crop reads served by L2",
                                              "algorithmic_bytes": nb, "median_us": us, "achieved_GBps": round(nb / us / 1e3, 1),
                                              "note": "byte work bound by the integer tap arithmetic (bit-exact Pillow fixed point), not by HBM"}
-        json.dump({"source": f"rocprofv3 --kernel-trace of `bench.py --streams 1` (profiles/{tag}_bench_streams1_kernel_stats.csv), tools/views_bench.py",
+        json.dump({"source": f"rocprofv3 --kernel-trace of `bench.py --streams 1` (profiles/{tag}_bench_kernel_stats_serialized.csv), tools/views_bench.py",
                    "kernels": k}, open(f"{out}/{tag}_hbm_kernels.json", "w"), indent=1)
     print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag + "_")))
 
