@@ -406,9 +406,12 @@ def test_fp16_operands_meet_the_1e3_tolerance(name):
             assert not grads[k].any(), k
             assert np.abs(lora1[k] - g["lora1/" + k]).max() < 1e-7, k
         else:
-            # (K = 1000 with every view selected: near-uniform predictions give gradients of ~1e-5; under the 2^10 loss scale the
-            #  attention-backward operands P*(dP - delta) of some heads fall into fp16's subnormal range -> up to 1e-2 on a tensor)
-            GT = 1e-2 if name == "b16_n64_k1000_ent0" else 4 * TOL
+            # Gradients: 4e-3 on every fixture.  What decides the figure is the 16-bit FORWARD, not this backward: an exact
+            # fp32 backward behind the same fp16-rounded forward sits at 7e-4 (8 views, K = 10), 3.0e-3 (64 views, K = 200) and
+            # 1.5e-3 (K = 1000) of each tensor's max (tools/fp16_grad_points.py -> profiles/r03_fp16_grad_points.txt): the
+            # loss gradient amplifies the 5e-4 logit deviation.  The K = 1000 / every-view-selected case used to sit at 8e-3
+            # (dS = P o (dP - delta) in fp16 subnormals under the 2^10 loss scale); dS is now pre-scaled by 2^8 (common.hpp).
+            GT = 4 * TOL
             assert max_rel(grads[k], gref) < GT, (k, max_rel(grads[k], gref))
             dg = np.abs(grads[k] - gref).max() * 1.001
             check_lora_step(lora1[k], g["lora1/" + k], gref, kw["lr"], TOL, k, dg=dg)

@@ -90,10 +90,15 @@ def test_text_mode_module_tree_matches_the_reference_names():
         m(torch.zeros(2, 3, 64, 64))
 
 
-def test_get_ttl_alias_and_rank_forwarding():
+def test_get_ttl_alias_and_rank_like_the_reference():
+    """get_coop drops ``rank`` exactly like the reference's (clip/custom_clip.py:706-721, Q7) unless told to honour it."""
     assert get_ttl is get_coop
+    with pytest.warns(UserWarning, match="dropped like in the reference"):
+        m = get_coop("tiny", "A", "cpu", 4, "a_photo_of_a", layer_range=[1, 3], init_method="xavier", lora_encoder="image",
+                     rank=32, classnames=["x", "y"])
+    assert m.trainable_lora_parameters()[0].shape == (16, 128)
     m = get_coop("tiny", "A", "cpu", 4, "a_photo_of_a", layer_range=[1, 3], init_method="xavier", lora_encoder="image",
-                 rank=32, classnames=["x", "y"])
+                 rank=32, classnames=["x", "y"], honour_rank=True)
     assert m.trainable_lora_parameters()[0].shape == (32, 128)
 
 

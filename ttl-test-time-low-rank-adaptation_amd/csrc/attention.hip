@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * kt + acc_row(r, lane);
                 float p = (key < T && !(causal && key > q)) ? __expf(s[r] * SCALE - l) : 0.f;
-                s[r] = p * (dp[r] - delta);  // dS^T
+                s[r] = p * (dp[r] - delta) * TTL_DS_PRESCALE;  // dS^T (pre-scaled by a power of two in the fp16 build: common.hpp)
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
                                                                      dq[dt], 0, 0, 0);
             }
         }
-        if (q < T) store_ot(dqkv + (size_t)(img * T + q) * ldd + head * 64, dq, SCALE, lane);
+        if (q < T) store_ot(dqkv + (size_t)(img * T + q) * ldd + head * 64, dq, SCALE * (1.0f / TTL_DS_PRESCALE), lane);
     }
 }
 
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
                 int qi = 32 * qt + acc_row(r, lane);
                 float p = (qi < T && !(causal && key > qi)) ? __expf(s[r] * SCALE - sLse[qi]) : 0.f;
                 s[r] = p;
-                ds[r] = p * (dp[r] - sDelta[qi]);
+                ds[r] = p * (dp[r] - sDelta[qi]) * TTL_DS_PRESCALE;
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
             const int D = H * 64;     // dqkv is row-major [tokens][dq | dk | dv | ...]: the A operand of the dX GEMM
             op_t* base = dqkv + (size_t)(img * T + key) * ldd + head * 64;
             store_ot(base + 2 * D, dv, 1.0f, lane);
-            if (NEED_DK) store_ot(base + D, dk, SCALE, lane);
+            if (NEED_DK) store_ot(base + D, dk, SCALE * (1.0f / TTL_DS_PRESCALE), lane);
         }
     }
 }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
         const float p = live ? __expf(s * SCALE - l0) : 0.f;
         // the MFMA path rounds P and dS to the operand type before the second products; same points here
         const float pb = op_to_f32(f32_to_op(p));
-        const float ds = live ? op_to_f32(f32_to_op(p * (dp - delta))) : 0.f;
+        const float ds = live ? op_to_f32(f32_to_op(p * (dp - delta) * TTL_DS_PRESCALE)) * (1.0f / TTL_DS_PRESCALE) : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq[e] = fmaf(ds, (float)kf[e], dq[e]);
         if (ok) {

@@ -13,12 +13,21 @@ typedef uint16_t op_t;  // storage type; arithmetic is always fp32
 typedef _Float16 op_scalar;
 #define TTL_OPERAND_NAME "fp16"
 #define TTL_GRAD_SCALE 1024.0f
+// Attention backward, dS = P o (dP - delta): the one gradient-side operand that is a product with a probability, so most of
+// its elements are orders of magnitude below the rest of the (loss-scaled) backward and fall into fp16's subnormal range
+// under the reference's 2^10 scale (K = 1000 with every view selected: one gradient tensor 8e-3 off; with dS kept exact
+// 1.5e-3, which is what the 16-bit FORWARD leaves: tools/fp16_grad_points.py, profiles/r03_fp16_grad_points.txt).  dS is
+// therefore rounded to fp16 as dS * 2^8 and the products that consume it (dQ = dS K, dK = dS^T Q) are scaled back by 2^-8 in
+// fp32: exact powers of two, no change to any other operand.  An overflow of the pre-scaled value is an inf in the
+// gradients like any other: found_inf, whole step skipped, loss scale halved (GradScaler contract).
+#define TTL_DS_PRESCALE 256.0f
 #define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
 #define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
 #else
 typedef __bf16 op_scalar;
 #define TTL_OPERAND_NAME "bf16"
 #define TTL_GRAD_SCALE 1.0f
+#define TTL_DS_PRESCALE 1.0f      // bf16 has fp32's exponent range
 #define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
 #define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
 #endif

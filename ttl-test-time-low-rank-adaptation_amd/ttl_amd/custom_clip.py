@@ -606,10 +606,20 @@ class ClipTestTimeTuning(nn.Module):
 
 
 def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, layer_range=[0, 11], init_method=None,
-             lora_encoder='text', rank=16, classnames=None, **kw):
-    """clip/custom_clip.py:706-723.  NOTE the reference drops ``rank`` here (always 16, SURVEY Q7);
-    this build forwards it.  ``classnames`` may be given directly (the reference looks them up
-    from its own dataset tables, which are out of scope)."""
+             lora_encoder='text', rank=16, classnames=None, honour_rank=None, **kw):
+    """clip/custom_clip.py:706-723.  The reference accepts ``rank`` and DROPS it (its ClipTestTimeTuning call does not pass
+    it on: every model it builds has rank 16) — so does this function by default, with a warning: a caller that
+    passes ``--rank 32`` through the unchanged ttl.py gets the model the reference would build.  ``honour_rank=True`` (or
+    TTL_HONOUR_RANK=1) forwards it instead — BASELINE.json's r = 32 configuration is otherwise reachable only through the
+    ClipTestTimeTuning constructor, which is how the fixtures were generated.  ``classnames`` may be given directly (the
+    reference looks them up from its own dataset tables, which are out of scope)."""
+    if honour_rank is None:
+        honour_rank = os.environ.get("TTL_HONOUR_RANK", "0") == "1"
+    if rank != 16 and not honour_rank:
+        import warnings
+        warnings.warn(f"get_coop: rank={rank} is dropped like in the reference (clip/custom_clip.py:720-721 builds rank 16); "
+                      f"pass honour_rank=True or set TTL_HONOUR_RANK=1 to build rank {rank}")
+        rank = 16
     if classnames is None:
         if test_set == 'bongard':
             classnames = ['X', 'X'] if learned_cls else ['True', 'False']
