@@ -150,20 +150,19 @@ def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
     # The reference recomputes the K class-text features in EVERY forward (clip/custom_clip.py:669-671, Q12): twice per
     # image.  Time the text tower's restatement on a few prompts and scale linearly in K for that figure.
     try:
-        from oracle import ttl_oracle as O
         from ttl_amd.config import get_text_config
         tcfg = get_text_config(cfg.name)
         Wt = synth.text_weights(tcfg, 0)
-        kp = min(n_classes, 32)
-        ids = synth.token_ids(kp, tcfg, 3)
-        net = O.TextOracle(tcfg, Wt, synth.lora_init(tcfg, 0, tower="text_model"), "fp32")
-        net.trained = lambda i: False
+        ids = synth.token_ids(n_classes, tcfg, 3)
+        torch.set_num_threads(cores)
+        OT.text_features_forward(tcfg, Wt, ids[:8])
         t0 = time.time()
-        net.forward(ids)
-        t_text = (time.time() - t0) * n_classes / kp
+        OT.text_features_forward(tcfg, Wt, ids)
+        t_text = time.time() - t0
+        torch.set_num_threads(prev)
         out["reference_faithful"] = {"value": round(1.0 / (dt + 2.0 * t_text), 5), "unit": "images/sec",
-                                     "note": f"+ 2 text-tower forwards of K={n_classes} prompts per image as the reference does "
-                                             f"(numpy restatement timed on {kp} prompts: {t_text:.1f} s per K-prompt forward after scaling)"}
+                                     "note": f"+ 2 text-tower forwards of the K={n_classes} prompts per image as the reference does "
+                                             f"(torch fp32, same threads: {t_text:.2f} s per K-prompt forward)"}
     except Exception as e:      # never let the secondary figure break the bench line
         out["reference_faithful"] = {"value": None, "note": f"not measured: {e}"}
     return out

@@ -124,6 +124,34 @@ class TorchTower:
         return self.scale * (f / f.norm(dim=-1, keepdim=True)) @ tfeat.T              # clip/custom_clip.py:679-687
 
 
+def text_features_forward(tcfg, Wt, ids):
+    """HF CLIP text tower in torch fp32, forward only (clip/custom_clip.py:651-663 get_text_features under no_grad when the
+    adapters sit on the image tower): token + position embeddings, causal pre-LN encoder, final_layer_norm, pooled at
+    argmax(input_ids), text_projection.  ids [K,T] int64 -> un-normalised features [K,E].  Checked against the numpy
+    TextOracle (itself pinned to reference-generated text fixtures) in tests/test_oracle_text_golden.py."""
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(Wt[k], dtype=np.float32))
+    ids = torch.as_tensor(np.asarray(ids), dtype=torch.int64)
+    K, T = ids.shape
+    D, Hh = tcfg.width, tcfg.heads
+    dh = D // Hh
+    with torch.no_grad():
+        h = t("text_model.embeddings.token_embedding.weight")[ids] + t("text_model.embeddings.position_embedding.weight")[:T]
+        mask = torch.full((T, T), float("-inf")).triu(1)
+        for i in range(tcfg.layers):
+            b = f"text_model.encoder.layers.{i}."
+            x1 = F.layer_norm(h, (D,), t(b + "layer_norm1.weight"), t(b + "layer_norm1.bias"), tcfg.ln_eps)
+            q, k, v = (F.linear(x1, t(b + f"self_attn.{pj}.weight"), t(b + f"self_attn.{pj}.bias")).reshape(K, T, Hh, dh).transpose(1, 2)
+                       for pj in ("q_proj", "k_proj", "v_proj"))
+            att = torch.softmax((q * dh ** -0.5) @ k.transpose(-1, -2) + mask, -1) @ v
+            h = h + F.linear(att.transpose(1, 2).reshape(K, T, D), t(b + "self_attn.out_proj.weight"), t(b + "self_attn.out_proj.bias"))
+            x2 = F.layer_norm(h, (D,), t(b + "layer_norm2.weight"), t(b + "layer_norm2.bias"), tcfg.ln_eps)
+            u = F.linear(x2, t(b + "mlp.fc1.weight"), t(b + "mlp.fc1.bias"))
+            h = h + F.linear(u * torch.sigmoid(1.702 * u), t(b + "mlp.fc2.weight"), t(b + "mlp.fc2.bias"))
+        pooled = h[torch.arange(K), ids.argmax(-1)]
+        y = F.layer_norm(pooled, (D,), t("text_model.final_layer_norm.weight"), t("text_model.final_layer_norm.bias"), tcfg.ln_eps)
+        return y @ t("text_projection.weight").T
+
+
 def softmax_entropy(z):                                                                # deyo.py:85-90
     return -(z.softmax(1) * z.log_softmax(1)).sum(1)
 

@@ -60,3 +60,22 @@ def test_causal_mask_and_eot_pooling_are_what_matters():
         ids2[k, e + 1:] = 7        # garbage (smaller than eot) after the pooled position
     b = O.TextOracle(TEXT_TINY, Wt, lora).forward(ids2)
     assert np.allclose(a, b, atol=1e-6)
+
+
+def test_torch_text_tower_equals_the_pinned_numpy_one():
+    """oracle/ttl_oracle_torch.text_features_forward (what bench.py's reference-faithful CPU figure times: the reference
+    recomputes the class-text features in every forward, clip/custom_clip.py:669-671) against TextOracle.forward — the numpy
+    text tower pinned to the reference-generated text fixtures above — on the tiny and the ViT-B/16 text geometries."""
+    pytest.importorskip("torch")
+    from oracle import ttl_oracle_torch as OT
+    from ttl_amd import synth
+    from ttl_amd.config import get_text_config
+    for arch, n in (("tiny", 12), ("ViT-B/16", 4)):
+        tcfg = get_text_config(arch)
+        Wt = synth.text_weights(tcfg, 0)
+        ids = synth.token_ids(n, tcfg, 3)
+        net = O.TextOracle(tcfg, Wt, synth.lora_init(tcfg, 0, tower="text_model"), "fp32")
+        net.trained = lambda i: False
+        want = net.forward(ids)
+        got = OT.text_features_forward(tcfg, Wt, ids).numpy()
+        assert max_rel(got, want) < 2e-5, (arch, max_rel(got, want))
