@@ -83,3 +83,42 @@ def load_text_case(name):
         if k.startswith("lora0/"):
             lora0[k[6:]] = g[k]
     return g, vcfg, tcfg, Wv, Wt, x, ids, lora0
+
+
+def write_tiny_hf_checkpoint(path, arch="tiny", seed=0):
+    """A locally WRITTEN HF-format CLIP checkpoint directory of a reduced geometry: config.json + model.safetensors from
+    ``save_pretrained`` and vocab.json / merges.txt of a byte-level CLIP BPE (256 byte symbols, their word-final forms, the two
+    specials) — what ``CLIPModel.from_pretrained`` / ``CLIPTokenizer.from_pretrained`` read at clip/custom_clip.py:581 of the
+    reference, without any download.  -> (the CLIPModel that was saved, vocab dict)."""
+    import json
+    import torch
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPConfig, CLIPModel
+    from ttl_amd.config import get_text_config
+    cfg, tcfg = get_config(arch), get_text_config(arch)
+    chars = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {t: i for i, t in enumerate(chars + [c + "</w>" for c in chars] + ["<|startoftext|>", "<|endoftext|>"])}
+    conf = CLIPConfig(
+        vision_config=dict(hidden_size=cfg.width, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                           image_size=cfg.image_size, patch_size=cfg.patch_size, projection_dim=cfg.embed, hidden_act="quick_gelu"),
+        text_config=dict(hidden_size=tcfg.width, intermediate_size=tcfg.mlp, num_hidden_layers=tcfg.layers, num_attention_heads=tcfg.heads,
+                         vocab_size=len(vocab), max_position_embeddings=77, projection_dim=cfg.embed, hidden_act="quick_gelu",
+                         bos_token_id=len(vocab) - 2, eos_token_id=len(vocab) - 1, pad_token_id=len(vocab) - 1),
+        projection_dim=cfg.embed)
+    gen = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    ref = CLIPModel(conf).float().eval()
+    with torch.no_grad():       # HF's default init gives near-identical features: spread the weights like synth.py does
+        for n, p in ref.named_parameters():
+            if p.dim() >= 2 and "embedding" not in n:
+                p.normal_(0, 1.2 / p.shape[-1] ** 0.5)
+    torch.random.set_rng_state(gen)
+    os.makedirs(path, exist_ok=True)
+    ref.save_pretrained(str(path))
+    with open(os.path.join(path, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(path, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n")
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "CLIPTokenizer", "model_max_length": 77}, f)
+    return ref, vocab

@@ -387,3 +387,48 @@ def test_coeff_pooling_branch():
     assert out.requires_grad
     out.logsumexp(1).sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.trainable_lora_parameters())
+
+
+def test_weights_from_a_local_hf_checkpoint_directory(tmp_path, monkeypatch):
+    """TTL_CLIP_WEIGHTS end to end (the reference's CLIPModel.from_pretrained, clip/custom_clip.py:581, with a local
+    directory): a locally written HF-format checkpoint of the `tiny` geometry -> ClipTestTimeTuning -> HIP context -> logits,
+    against the oracle on the tensors that were saved, with the class-text features of the checkpoint's own text tower
+    (HF forward) and its tokenizer; then one adaptation step moves the logits."""
+    from helpers import write_tiny_hf_checkpoint
+    from oracle import ttl_oracle as O
+    from ttl_amd import synth
+    from ttl_amd.config import get_config
+    from ttl_amd.custom_clip import ClipTestTimeTuning
+    from ttl_amd.ttl import test_time_tuning
+    ref, vocab = write_tiny_hf_checkpoint(str(tmp_path / "clip-tiny"), seed=3)
+    monkeypatch.setenv("TTL_CLIP_WEIGHTS", str(tmp_path / "clip-tiny"))
+    cfg = get_config("tiny")
+    names = ["cat", "dog", "frog"]
+    model = ClipTestTimeTuning(0, names, None, arch="tiny", layer_range=[cfg.layer_lo, cfg.layer_hi], init_method="xavier",
+                               lora_encoder="image", max_views=8, max_classes=3)
+    model.eval()
+    x = synth.views(cfg, 8, 5)
+    with torch.no_grad():
+        z = model(torch.from_numpy(x).cuda()).cpu().numpy()
+    # the oracle on the checkpoint's tensors; text features through the saved HF text tower
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    W = {k: v for k, v in sd.items() if (k.startswith("vision_model.") or k == "visual_projection.weight") and "position_ids" not in k}
+    W["logit_scale"] = sd["logit_scale"]
+    lora = {k.replace("image_encoder.", ""): p.detach().cpu().numpy() for k, p in model.named_parameters() if "lora_" in k}
+    ids = model.prompt_learner.tokenized_prompts
+    assert tuple(ids.shape) == (3, 77) and int(ids.max()) == len(vocab) - 1
+    with torch.no_grad():
+        t = ref.get_text_features(input_ids=ids.cpu())
+        t = getattr(t, "pooler_output", t)
+        t = (t / t.norm(dim=-1, keepdim=True)).numpy()
+    net = O.VitOracle(cfg, W, lora, "fp32")
+    want = net.logits(net.forward(x), t)
+    assert max_rel(z, want) < 3e-2, max_rel(z, want)          # bf16 operands on the D = 128 toy (cf. test_forward_logits)
+    assert np.array_equal(z.argmax(1), want.argmax(1)) or max_rel(z, want) < 1e-2
+    for n_, p in model.named_parameters():
+        p.requires_grad_("lora_" in n_ and any(f"layers.{i}." in n_ for i in range(cfg.layer_lo, cfg.layer_hi + 1)))
+    opt = torch.optim.AdamW([{"params": [p]} for p in model.trainable_lora_parameters()], lr=5e-3)
+    test_time_tuning(model, torch.from_numpy(x).cuda(), opt, torch.amp.GradScaler("cuda", init_scale=1000), ref_args())
+    with torch.no_grad():
+        z1 = model(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(z1 - z).max() > 1e-4

@@ -207,31 +207,15 @@ def test_hf_checkpoint_directory_loader(tmp_path):
     geometry: config.json + model.safetensors from save_pretrained, vocab.json + merges.txt of a byte-level CLIP BPE.  The
     vision state that comes back must be exactly the tensor set (names, shapes) the HIP context loads by name, with the
     checkpoint's values; the tokenizer must produce [n, 77] ids whose arg-max is the end-of-text token."""
-    import json
     import numpy as np
     import torch
-    from transformers import CLIPConfig, CLIPModel
-    from tokenizers import pre_tokenizers
+    from helpers import write_tiny_hf_checkpoint
     from ttl_amd import synth
-    from ttl_amd.config import get_config, get_text_config
+    from ttl_amd.config import get_config
     from ttl_amd.custom_clip import _build_clip
-    cfg, tcfg = get_config("tiny"), get_text_config("tiny")
-    chars = sorted(pre_tokenizers.ByteLevel.alphabet())          # the 256 byte-level symbols of the CLIP BPE
-    vocab = {t: i for i, t in enumerate(chars + [c + "</w>" for c in chars] + ["<|startoftext|>", "<|endoftext|>"])}
-    conf = CLIPConfig(
-        vision_config=dict(hidden_size=cfg.width, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
-                           image_size=cfg.image_size, patch_size=cfg.patch_size, projection_dim=cfg.embed, hidden_act="quick_gelu"),
-        text_config=dict(hidden_size=tcfg.width, intermediate_size=tcfg.mlp, num_hidden_layers=tcfg.layers, num_attention_heads=tcfg.heads,
-                         vocab_size=len(vocab), max_position_embeddings=77, projection_dim=cfg.embed, hidden_act="quick_gelu",
-                         bos_token_id=len(vocab) - 2, eos_token_id=len(vocab) - 1, pad_token_id=len(vocab) - 1),
-        projection_dim=cfg.embed)
-    torch.manual_seed(0)
-    ref = CLIPModel(conf).float().eval()
+    cfg = get_config("tiny")
     d = tmp_path / "clip-tiny"
-    ref.save_pretrained(str(d))
-    (d / "vocab.json").write_text(json.dumps(vocab))
-    (d / "merges.txt").write_text("#version: 0.2\n")
-    (d / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "CLIPTokenizer", "model_max_length": 77}))
+    ref, vocab = write_tiny_hf_checkpoint(str(d))
     model, vis, tokenizer = _build_clip(cfg, str(d), 0)
     want = synth.vision_weights(cfg, 0)                      # the name / shape set the context's loader knows (SURVEY appendix B)
     assert set(vis) == set(want), sorted(set(vis) ^ set(want))
