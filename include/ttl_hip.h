@@ -80,7 +80,9 @@ void ttl_ctx_destroy(ttl_ctx* ctx);
  * images), and the frozen weight images — everything but the projection images of the layers that carry adapters, whose
  * LoRA K-extension columns each context refreshes from its own adapters — are the parent's, read-only.  `parent` must own its
  * weights (not itself shared), have them all loaded (ttl_weights_ready), have the same model configuration as `cfg`
- * (max_views / max_classes may differ) and outlive `*out`.  ttl_load_weight on the new context is an error. */
+ * (max_views / max_classes may differ).  The parent's memory is reference-counted: it is released when the parent AND every context
+ * sharing its images have been destroyed, in whatever order (a destroyed parent must still not be USED).  ttl_load_weight on the new
+ * context is an error. */
 int ttl_ctx_create_shared(const ttl_config* cfg, ttl_ctx* parent, ttl_ctx** out);
 
 /* Load one fp32 tensor of the HF vision tower by its state-dict name,

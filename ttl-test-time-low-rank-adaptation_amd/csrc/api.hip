@@ -14,6 +14,7 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -81,7 +82,9 @@ struct ttl_ctx {
     // ext = K-extension columns of the QKV GEMMs (nqkv*r rounded up to 64), ldh = pitch of the bf16 stream-gradient buffers
     int tg, ntg, nqkv, sq, sk, sv, has_o, ext, ldh;
     int Mmax;
-    const ttl_ctx* parent = nullptr;        // != null: frozen weight images are the parent's (ttl_ctx_create_shared); read-only here
+    ttl_ctx* parent = nullptr;              // != null: frozen weight images are the parent's (ttl_ctx_create_shared); read-only here
+    std::atomic<int> refs{1};               // the owner's handle + one per context sharing this one's weight images: the memory
+                                            // goes when the last of them is destroyed, whatever the order of the destroy calls
     int use_hm = 0; unsigned hm_magic = 0;   // head-major q/k/v from the big-M QKV GEMM (TTL_QKV_HEAD_MAJOR=0: row-major everywhere)
     float scaling;
     std::vector<void*> allocs;
@@ -296,6 +299,7 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
     ttl_ctx* c = new ttl_ctx();
     set_geometry(c, k);
     c->parent = parent;
+    if (parent) parent->refs.fetch_add(1);
     const size_t D = c->D, F = c->F, M = c->Mmax, E = c->E, N = k->max_views, T = c->T, H = c->H, r = c->r;
     // frozen tensor: the parent's image (never written after loading) or an allocation of this context's own
 #define WSHARE(dst, src, count, zero) do { if (parent) (dst) = (src); else ALLOC(dst, count, zero); } while (0)
@@ -397,12 +401,19 @@ int ttl_ctx_create_shared(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) {
     return ctx_create_impl(k, parent, out);
 }
 
-void ttl_ctx_destroy(ttl_ctx* c) {
-    if (!c) return;
-    (void)hipDeviceSynchronize();
+static void ctx_release(ttl_ctx* c) {
+    if (c->refs.fetch_sub(1) != 1) return;          // contexts sharing its weight images are still alive
+    ttl_ctx* parent = c->parent;
     for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
+    if (parent) ctx_release(parent);
+}
+
+void ttl_ctx_destroy(ttl_ctx* c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    ctx_release(c);
 }
 
 // ------------------------------------------------------------------------------ weights

@@ -169,7 +169,17 @@ static void image_tower(const Geo& g) {
     bad = cfg; bad.layer_lo = cfg.layer_lo > 0 ? cfg.layer_lo - 1 : cfg.layer_lo + 1; bad.layer_hi = cfg.layer_hi;
     if (bad.layer_lo <= bad.layer_hi) EXPECT(ttl_ctx_create_shared(&bad, c, &sh) != 0);                              // another model
     EXPECT(ttl_ctx_create_shared(&cfg, nullptr, &sh) != 0);
+    // ---- destroy order: the owner goes FIRST, the sharing context keeps computing on the (reference-counted) weight images
+    ttl_ctx* late = nullptr;
+    EXPECT(ttl_ctx_create_shared(&cfg, c, &late) == 0 && late);
     ttl_ctx_destroy(c);
+    if (late) {
+        EXPECT(ttl_set_text_features(late, tf.data(), g.K, 100.f, nullptr) == 0);
+        std::vector<float> lora3 = snap, grads3(nl);
+        EXPECT(ttl_bind_lora(late, lora3.data(), grads3.data(), nl) == 0);
+        EXPECT(ttl_episode(late, &a, nullptr) == 0);
+        ttl_ctx_destroy(late);
+    }
 }
 
 static void text_tower(const Geo& g) {
