@@ -313,6 +313,9 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
                             op_t* y_bf16, int ld_bf16, float* mean, float* rstd, int rows, int D, float eps,
                             hipStream_t s, const int* rowmap) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+#ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no big LayerNorm forward launches
+    if ((TTL_DIAG_SKIP & 1) && rows >= 4096) return hipSuccess;
+#endif
     // several rows per wave only where there are rows to spare (big launches); small ones stay one row per wave
     if (TTL_LN_RPW > 1 && rows >= 4096)
         hipLaunchKernelGGL((ln_fwd_kernel<TTL_LN_RPW>), dim3((rows + 4 * TTL_LN_RPW - 1) / (4 * TTL_LN_RPW)), dim3(256), 0, s, x, row_stride,

@@ -346,6 +346,10 @@ bool gemm_takes_big(GemmEpi epi, const GemmArgs& a) {
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     if (a0.M <= 0 || a0.N % 128 || a0.K % BK || a0.K <= 0 || (a0.lda & 7) || (a0.ldb & 7)) return hipErrorInvalidValue;
     if ((a0.amap || a0.cmap || a0.c2map) && a0.M >= 1024) return hipErrorInvalidValue;   // row maps: guarded small-M kernels only
+#ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no small-M launches, bit 1 = no big-M ones
+    if ((TTL_DIAG_SKIP & 1) && a0.M < 1024) return hipSuccess;
+    if ((TTL_DIAG_SKIP & 2) && a0.M >= 1024) return hipSuccess;
+#endif
     GemmArgs a = a0;
     a.splits = 1;
     // Small-M, long-K, fp32-output calls (fc2 / dx of the 1-view inference and of the CLS-only top-layer
