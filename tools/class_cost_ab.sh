@@ -6,11 +6,15 @@
 #   bash tools/class_cost_ab.sh       (on the GPU box; -> gpurun_out/class_cost.txt)
 cd "$(dirname "$0")/.."
 bash tools/hip_variant.sh attention TTL_DIAG_SKIP=1 TTL_DIAG_SKIP=2 > /dev/null
-bash tools/hip_variant.sh elementwise TTL_DIAG_SKIP=1 > /dev/null
+bash tools/hip_variant.sh elementwise TTL_DIAG_SKIP=1 TTL_DIAG_SKIP=2 > /dev/null
+bash tools/hip_variant.sh head_loss TTL_DIAG_SKIP=1 > /dev/null
 bash tools/hip_variant.sh lora TTL_DIAG_SKIP=3 > /dev/null
 bash tools/hip_variant.sh gemm TTL_DIAG_SKIP=1 TTL_DIAG_SKIP=2 > /dev/null
 mkdir -p gpurun_out
-Q="--no-cpu-baseline --no-parity --no-fp16-leg --steps 150 --repeats 3"
+# plain launches (a captured graph would keep the launches that were issued at capture time); every variant issues its class
+# normally through the warm-up and the first part of the first timed block, so the buffers downstream hold realistic data; the
+# median of the three blocks is a block in which the class is not issued
+Q="--no-cpu-baseline --no-parity --no-fp16-leg --steps 150 --repeats 3 --graph 0"
 run() { TTL_HIP_LIB_BF16=$2 python bench.py $Q 2>/dev/null | python -c "
 import sys, json
 d = [json.loads(l) for l in sys.stdin if l.startswith('{')][-1]
@@ -20,6 +24,8 @@ run "product" ""
 run "no dense attention forward" tools/_diag/libttl_hip_attention_TTL_DIAG_SKIP_1.so
 run "no dense attention backward" tools/_diag/libttl_hip_attention_TTL_DIAG_SKIP_2.so
 run "no big LayerNorm forward" tools/_diag/libttl_hip_elementwise_TTL_DIAG_SKIP_1.so
+run "no big LayerNorm backward" tools/_diag/libttl_hip_elementwise_TTL_DIAG_SKIP_2.so
+run "no head forward / backward" tools/_diag/libttl_hip_head_loss_TTL_DIAG_SKIP_1.so
 run "no big LoRA skinny / wgrad" tools/_diag/libttl_hip_lora_TTL_DIAG_SKIP_3.so
 run "no small-M GEMM launches" tools/_diag/libttl_hip_gemm_TTL_DIAG_SKIP_1.so
 run "no big-M GEMM launches" tools/_diag/libttl_hip_gemm_TTL_DIAG_SKIP_2.so

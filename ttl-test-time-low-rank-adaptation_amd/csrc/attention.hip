@@ -285,11 +285,9 @@ __global__ __launch_bounds__(64 * NKT, 4) void attn_fwd_w_kernel(const op_t* __r
 #ifndef TTL_ATTN_DIAG
 #define TTL_ATTN_DIAG 0
 #endif
-// Timing-only ablation of the EPISODE (tools/class_cost_ab.sh; results wrong on purpose): bit 0 = the dense forward launches are
-// not issued, bit 1 = the dense backward launches.  What the rate gains says what that kernel class costs with three episodes in flight.
-#ifndef TTL_DIAG_SKIP
-#define TTL_DIAG_SKIP 0
-#endif
+// (-DTTL_DIAG_SKIP=bits, tools/class_cost_ab.sh: timing-only ablation of the EPISODE, results wrong on purpose: bit 0 = the dense
+// forward launches stop being issued after the warm-up, bit 1 = the dense backward launches)
+
 // 16 B per lane, global -> LDS (M0 = wave-uniform LDS base, lane-linear destination), invisible to hipcc's wait-count pass
 __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) {
     const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds);
@@ -838,7 +836,9 @@ hipError_t bwd_t(const op_t* qkv, QkvLayout ld, const op_t* out, const op_t* dou
 
 hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                 hipStream_t s, int causal) {
-    if ((TTL_DIAG_SKIP & 1) && n * H >= 512) return hipSuccess;
+#ifdef TTL_DIAG_SKIP
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && n * H >= 512 && diag_skip_now(cnt, 440)) return hipSuccess; }
+#endif
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return fwd_t<1>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
@@ -862,7 +862,9 @@ hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout ld_qkv, op_t* out, in
 hipError_t launch_attention_bwd(const op_t* qkv, QkvLayout ld_qkv, const op_t* out, const op_t* dout, int ld_o,
                                 const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                 hipStream_t s, int causal) {
-    if ((TTL_DIAG_SKIP & 2) && n * H >= 512) return hipSuccess;
+#ifdef TTL_DIAG_SKIP
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && n * H >= 512 && diag_skip_now(cnt, 80)) return hipSuccess; }
+#endif
     int nkt = (T + 31) / 32;
     if (nkt <= 1) return bwd_t<1>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);
     if (nkt <= 2) return bwd_t<2>(qkv, ld_qkv, out, dout, ld_o, lse, dqkv, ld_dqkv, n, T, H, need_dk, s, causal);

@@ -314,7 +314,7 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
                             hipStream_t s, const int* rowmap) {
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
 #ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no big LayerNorm forward launches
-    if ((TTL_DIAG_SKIP & 1) && rows >= 4096) return hipSuccess;
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && rows >= 4096 && diag_skip_now(cnt, 1320)) return hipSuccess; }
 #endif
     // several rows per wave only where there are rows to spare (big launches); small ones stay one row per wave
     if (TTL_LN_RPW > 1 && rows >= 4096)
@@ -330,6 +330,9 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* me
                                 const float* gamma, const float* dres, float* out_f32, op_t* out_bf16, int rows,
                                 int D, hipStream_t s, long long x_stride, long long o_stride, int stat_stride,
                                 int dres_T, const int* pool, long long ld_bf16) {
+#ifdef TTL_DIAG_SKIP       // bit 1 = no big LayerNorm backward launches (after the warm-up)
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && rows >= 4096 && diag_skip_now(cnt, 240)) return hipSuccess; }
+#endif
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
                        out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D,

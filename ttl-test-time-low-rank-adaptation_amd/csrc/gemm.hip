@@ -347,8 +347,8 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     if (a0.M <= 0 || a0.N % 128 || a0.K % BK || a0.K <= 0 || (a0.lda & 7) || (a0.ldb & 7)) return hipErrorInvalidValue;
     if ((a0.amap || a0.cmap || a0.c2map) && a0.M >= 1024) return hipErrorInvalidValue;   // row maps: guarded small-M kernels only
 #ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no small-M launches, bit 1 = no big-M ones
-    if ((TTL_DIAG_SKIP & 1) && a0.M < 1024) return hipSuccess;
-    if ((TTL_DIAG_SKIP & 2) && a0.M >= 1024) return hipSuccess;
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && a0.M < 1024 && diag_skip_now(cnt, 1200)) return hipSuccess; }
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && a0.M >= 1024 && diag_skip_now(cnt, 2200)) return hipSuccess; }
 #endif
     GemmArgs a = a0;
     a.splits = 1;

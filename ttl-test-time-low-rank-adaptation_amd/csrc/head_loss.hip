@@ -359,6 +359,9 @@ __global__ void reset_kernel(float* __restrict__ p, const float* __restrict__ sn
 }  // namespace
 
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t s) {
+#ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no head forward / backward launches
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && diag_skip_now(cnt, 80)) return hipSuccess; }
+#endif
     hipError_t e = launch_layernorm(a.h, (long long)a.T * a.D, a.ln_g, a.ln_b, a.y, nullptr, 0, a.cls_mean, a.cls_rstd, n, a.D,
                                     a.eps, s);
     if (e != hipSuccess) return e;
@@ -373,6 +376,9 @@ hipError_t launch_head_logits(const HeadArgs& a, int n, hipStream_t s) {
 }
 
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dh, op_t* dh16, int n, hipStream_t s) {
+#ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no head forward / backward launches
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && diag_skip_now(cnt, 40)) return hipSuccess; }
+#endif
     hipLaunchKernelGGL(head_dfh_kernel, dim3((a.E + HO - 1) / HO, n), dim3(HB), a.K * sizeof(float), s, a, dlogits);
     hipLaunchKernelGGL(head_dy_kernel, dim3((a.D + HO - 1) / HO, n), dim3(HB), a.E * sizeof(float), s, a);
     hipError_t e = hipGetLastError();

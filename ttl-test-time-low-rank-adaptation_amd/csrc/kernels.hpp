@@ -19,6 +19,12 @@ inline hipError_t ensure_smem(const void* fn, int bytes, std::atomic<uint64_t>& 
     done.fetch_or(bit, std::memory_order_release);
     return hipSuccess;
 }
+#ifdef TTL_DIAG_SKIP
+// Timing-only ablations of the episode (tools/class_cost_ab.sh; never defined in the product build): a call site stops issuing its
+// launches after `after` of them, i.e. once the buffers downstream hold realistic data from the warm-up (all-zero MFMA operands
+// would raise the clock and flatter the remaining kernels).
+inline bool diag_skip_now(std::atomic<int>& n, int after) { return n.fetch_add(1) >= after; }
+#endif
 // CU count of the CURRENT device (cached per device), 0 on error
 inline int device_cu_count() {
     static std::atomic<int> ncu[64];

@@ -216,7 +216,7 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
                               op_t* out, long long ldo, int M, hipStream_t s, const int* rowmap) {
     if (ntg < 1 || ntg > 3) return hipErrorInvalidValue;
 #ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no big skinny products, bit 1 = no wgrad
-    if ((TTL_DIAG_SKIP & 1) && M >= 4096) return hipSuccess;
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && M >= 4096 && diag_skip_now(cnt, 360)) return hipSuccess; }
 #endif
     const int3 xo = {xoff[0], ntg > 1 ? xoff[1] : 0, ntg > 2 ? xoff[2] : 0};
     const int ncg = r / 16, ks = D / 32;
@@ -234,7 +234,7 @@ int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
 hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* partial, hipStream_t s, const float* scaler_f, int* scaler_i) {
     if (D % WG_BN || L.n < 1 || L.n > WGRAD_MAX) return hipErrorInvalidValue;
 #ifdef TTL_DIAG_SKIP
-    if ((TTL_DIAG_SKIP & 2) && M >= 4096) return hipSuccess;
+    { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && M >= 4096 && diag_skip_now(cnt, 120)) return hipSuccess; }
 #endif
     const int nch = lora_wgrad_chunks(M);
     dim3 grid(nch, D / WG_BN, L.n);
