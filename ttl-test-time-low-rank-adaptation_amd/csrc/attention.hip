@@ -504,7 +504,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
             for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
         }
         delta += __shfl_xor(delta, 32, 64);
-        const float l = lse[((size_t)img * H + head) * T + qrow];
+        // p = exp(s/8 - lse) as exp2(s*C2 - lse*log2 e): one fma + v_exp_f32 per element (the forward's form)
+        constexpr float LOG2E = 1.4426950408889634f, C2 = SCALE * LOG2E;
+        const float l = lse[((size_t)img * H + head) * T + qrow] * LOG2E;
         f32x16 dq[2] = {};
 #pragma unroll 1
         for (int kt = 0; kt < NKT; ++kt) {
@@ -515,11 +517,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const op_t* __rest
                 s = MFMA32(row_frag(sK, 32 * kt, ks, lane), qf[ks], s, 0, 0, 0);
                 dp = MFMA32(row_frag(sV, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
             }
+            // only the tile that holds keys >= T (the last one) and, in the causal tower, the tiles at or past the query block
+            // need the per-element mask: a wave-uniform branch keeps the compares and selects out of the other tiles
+            if (32 * kt + 32 > T || (causal && kt >= qb)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * kt + acc_row(r, lane);
-                float p = (key < T && !(causal && key > q)) ? __expf(s[r] * SCALE - l) : 0.f;
-                s[r] = p * (dp[r] - delta) * TTL_DS_PRESCALE;  // dS^T (pre-scaled by a power of two in the fp16 build: common.hpp)
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kt + acc_row(r, lane);
+                    float p = (key < T && !(causal && key > q)) ? __builtin_amdgcn_exp2f(fmaf(s[r], C2, -l)) : 0.f;
+                    s[r] = p * (dp[r] - delta) * TTL_DS_PRESCALE;  // dS^T (pre-scaled by a power of two in the fp16 build: common.hpp)
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], C2, -l)) * (dp[r] - delta) * TTL_DS_PRESCALE;
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
             for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)b[j];
         }
         sDelta[t] = d;
-        sLse[t] = lse[((size_t)img * H + head) * T + row];
+        sLse[t] = lse[((size_t)img * H + head) * T + row] * 1.4426950408889634f;     // in base 2: p = exp2(s*C2 - lse*log2 e)
     }
     __syncthreads();
 
@@ -592,12 +601,23 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
                 dp = MFMA32(row_frag(sDO, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
             }
             f32x16 ds;
+            // (per-element mask only in the query tile that holds rows >= T and, causal, in the tiles at or before the key block)
+            if (32 * qt + 32 > T || (causal && qt <= kb)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int qi = 32 * qt + acc_row(r, lane);
-                float p = (qi < T && !(causal && key > qi)) ? __expf(s[r] * SCALE - sLse[qi]) : 0.f;
-                s[r] = p;
-                ds[r] = p * (dp[r] - sDelta[qi]) * TTL_DS_PRESCALE;
+                for (int r = 0; r < 16; ++r) {
+                    int qi = 32 * qt + acc_row(r, lane);
+                    float p = (qi < T && !(causal && key > qi)) ? __builtin_amdgcn_exp2f(fmaf(s[r], SCALE * 1.4426950408889634f, -sLse[qi])) : 0.f;
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - sDelta[qi]) * TTL_DS_PRESCALE;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = 32 * qt + acc_row(r, lane);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE * 1.4426950408889634f, -sLse[qi]));
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - sDelta[qi]) * TTL_DS_PRESCALE;
+                }
             }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
