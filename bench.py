@@ -302,7 +302,7 @@ def main():
         """one timed block: this rank's items of a stream of world * n_items -> (wall s, max over ranks; s spent in submit())"""
         t0 = time.perf_counter()
         for i in shard.indices(world * n_items):
-            pipe.submit(pool[item(i)], target=labels[item(i)], n_updates=a.updates)
+            pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, n_updates=a.updates)
         t_enq = time.perf_counter() - t0
         fence(pipe)
         dt = time.perf_counter() - t0
@@ -365,7 +365,7 @@ def main():
 
         def run_all():
             for i in range(nprof):
-                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], n_updates=a.updates)
+                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], persistent_input=True, n_updates=a.updates)
             pipe.synchronize()
 
         def run_one():

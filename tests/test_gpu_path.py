@@ -459,15 +459,19 @@ def test_episode_as_hip_graph_replays_bit_identically():
     assert torch.equal(out1, ref1) and torch.equal(out0, ref0)
     eng.close()
     # pipeline with use_graph: same hits and logits as without
+    # ... and with persistent_input=True (one graph per pre-staged input buffer, replayed in place: what bench.py does)
     outs = {}
-    for ug in (False, True):
+    for ug, keep in ((False, False), (True, False), (True, True)):
         pipe = EpisodePipeline(cfg, W, names, lora0, torch.from_numpy(tf), float(np.exp(W["logit_scale"])), "cuda:0",
                                n_streams=2, max_views=x.shape[0], use_graph=ug)
-        res = [pipe.submit(xx, target=torch.tensor([3], device="cuda"), n_updates=1) for xx in (x0, x1, x0, x1, x1)]
+        res = [pipe.submit(xx, target=torch.tensor([3], device="cuda"), persistent_input=keep, n_updates=1) for xx in (x0, x1, x0, x1, x1, x0)]
         pipe.synchronize()
-        outs[ug] = (torch.stack(res).cpu(), pipe.totals().cpu())
+        outs[(ug, keep)] = (torch.stack(res).cpu(), pipe.totals().cpu())
+        if keep:
+            assert all(len(sl["graphs_in_place"]) == 2 and sl["graph"] is None for sl in pipe.slots)
         pipe.close()
-    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    for k in ((True, False), (True, True)):
+        assert torch.equal(outs[(False, False)][0], outs[k][0]) and torch.equal(outs[(False, False)][1], outs[k][1]), k
 
 
 def test_three_episodes_in_flight_are_bitwise_repeatable():

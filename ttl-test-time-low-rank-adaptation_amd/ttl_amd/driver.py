@@ -299,11 +299,13 @@ class EpisodePipeline:
         self._next = 0
         torch.cuda.synchronize(self.slots[0]["flat"].device)
 
-    def submit(self, views, target=None, **episode_kw):
+    def submit(self, views, target=None, persistent_input=False, **episode_kw):
         """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K].
         With ``target`` (device int64 [1]) the slot's [hits1, hits5, count] accumulator is updated on
         the same stream (no host sync).  The caller must not overwrite ``views`` until the slot's
-        stream has caught up."""
+        stream has caught up.  ``persistent_input`` (graph replay only): ``views`` is a buffer the caller keeps alive and
+        re-submits (bench.py's pre-staged batches) — the slot captures one graph per such buffer and replays it in place,
+        instead of copying every batch into the slot's own input buffer first (38.5 MB per image at 64 views)."""
         sl = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         sl["stream"].wait_stream(torch.cuda.current_stream())
@@ -313,12 +315,21 @@ class EpisodePipeline:
         with torch.cuda.stream(sl["stream"]):
             if self.use_graph:
                 key = (tuple(views.shape), tuple(sorted(episode_kw.items())))
-                if sl.get("gkey") != key:
-                    sl["xbuf"] = torch.empty_like(views)
+                if sl.get("gkey") != key:          # another shape / argument set: every captured graph of the slot is stale
+                    sl["gkey"], sl["graph"], sl["xbuf"], sl["graphs_in_place"] = key, None, None, {}
                     sl["obuf"] = torch.empty((1, sl["eng"].n_classes), dtype=torch.float32, device=views.device)
+                inplace = sl["graphs_in_place"]
+                if persistent_input and (views.data_ptr() in inplace or len(inplace) < 16):
+                    g = inplace.get(views.data_ptr())
+                    if g is None:                   # (the capture runs this episode already)
+                        g = inplace[views.data_ptr()] = (sl["eng"].episode_graph(views, sl["snap"], sl["m"], sl["v"], sl["obuf"], **episode_kw), views)
+                        out = sl["obuf"].clone()
+                    else:
+                        out = g[0]().clone()
+                elif sl["graph"] is None:
+                    sl["xbuf"] = torch.empty_like(views)
                     sl["xbuf"].copy_(views)
                     sl["graph"] = sl["eng"].episode_graph(sl["xbuf"], sl["snap"], sl["m"], sl["v"], sl["obuf"], **episode_kw)
-                    sl["gkey"] = key
                     out = sl["obuf"].clone()          # the capture ran this episode already
                 else:
                     sl["xbuf"].copy_(views, non_blocking=True)
