@@ -269,8 +269,8 @@ size_t ttl_workspace_bytes(const ttl_config* k) {
     const size_t ldo = D + (t.has_o ? 64 : 0);
     size_t w = L * (3 * D * t.ldw + D * ldo + 2 * D * F) * 2 + nT * (D * t.ldwt + D * ldo + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
                (t.text ? (size_t)k->vocab_size * D * 4 : 0);
-    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + M * 3 * D + M * ldo + M * F) * 2 +
-                 (M * D + M * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * 2 +
+    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + (M + t.T) * 3 * D + M * ldo + M * F) * 2 +
+                 (M * D + (M + t.T) * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * 2 +
                  (size_t)lora_wgrad_chunks((int)M) * 2 * t.ntg * t.r * D * 4;
     return w + act;
 }
