@@ -10,7 +10,18 @@
 
 namespace {
 
-constexpr int HB = 256;  // threads per head block
+// Slices of a mat-vec's reduction per block (HB = 64 * slices threads).  Every head kernel is a serial walk of I / slices
+// terms per thread behind L2 round trips (25 us for a 64 x 768 x 512 product with 4 slices, the SAME 24 us for one view).
+// Measured (round 3, tools/hip_variant.sh head_loss TTL_HEAD_SLICES=..., three leases of bench.py each): 16 slices cut the
+// class from 0.158 to 0.098 ms per episode one at a time, 8 slices to 0.114 — and move the rate with three episodes in flight
+// by +0.3 % (289.4 vs 288.6 images/s, inside the spread): the class is only 45 % exposed.  The fp32 summation order of the
+// logits changes with the slice count, so the default stays at round 2's 4 (the fixtures' adapted logits sit on sign-like
+// AdamW steps and move at the 1e-3 level with any perturbation of the last bit).
+#ifndef TTL_HEAD_SLICES
+#define TTL_HEAD_SLICES 4
+#endif
+constexpr int NS = TTL_HEAD_SLICES;
+constexpr int HB = 64 * NS;  // threads per head block
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -47,24 +58,28 @@ __device__ __forceinline__ float matvec64(const float* __restrict__ in_lds, cons
         int i = slice;
         // (8-fold unrolling for 32 loads in flight per thread was tried: the class got 2x SLOWER in situ)
 #pragma unroll 2
-        for (; i + 12 < I; i += 16) {
+        for (; i + 3 * NS < I; i += 4 * NS) {
             a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
-            a1 = fmaf(in_lds[i + 4], w[(size_t)(i + 4) * O], a1);
-            a2 = fmaf(in_lds[i + 8], w[(size_t)(i + 8) * O], a2);
-            a3 = fmaf(in_lds[i + 12], w[(size_t)(i + 12) * O], a3);
+            a1 = fmaf(in_lds[i + NS], w[(size_t)(i + NS) * O], a1);
+            a2 = fmaf(in_lds[i + 2 * NS], w[(size_t)(i + 2 * NS) * O], a2);
+            a3 = fmaf(in_lds[i + 3 * NS], w[(size_t)(i + 3 * NS) * O], a3);
         }
-        for (; i < I; i += 4) a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
+        for (; i < I; i += NS) a0 = fmaf(in_lds[i], w[(size_t)i * O], a0);
     }
     part[slice][threadIdx.x & (HO - 1)] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    return (part[0][threadIdx.x & (HO - 1)] + part[1][threadIdx.x & (HO - 1)]) +
-           (part[2][threadIdx.x & (HO - 1)] + part[3][threadIdx.x & (HO - 1)]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; k += 4)      // fixed order: deterministic
+        t += (part[k][threadIdx.x & (HO - 1)] + part[k + 1][threadIdx.x & (HO - 1)]) +
+             (part[k + 2][threadIdx.x & (HO - 1)] + part[k + 3][threadIdx.x & (HO - 1)]);
+    return t;
 }
 
 // grid (ceil(E/64), n): f[v][e] = sum_d y[v][d] * WpT[d][e]
 __global__ __launch_bounds__(HB) void head_proj_kernel(HeadArgs a) {
     extern __shared__ float sm[];
-    __shared__ float part[4][HO];
+    __shared__ float part[NS][HO];
     const int v = blockIdx.y, e = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < a.D; d += HB) sm[d] = a.y[(size_t)v * a.D + d];
     __syncthreads();
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(HB) void head_proj_kernel(HeadArgs a) {
 __global__ __launch_bounds__(HB) void head_logits_kernel(HeadArgs a) {
     extern __shared__ float sm[];
     __shared__ float red[HB / 64];
-    __shared__ float part[4][HO];
+    __shared__ float part[NS][HO];
     const int v = blockIdx.y, k = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     float nn = 0.f;
     for (int e = threadIdx.x; e < a.E; e += HB) { float t = a.f[(size_t)v * a.E + e]; sm[e] = t; nn += t * t; }
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(HB) void head_logits_kernel(HeadArgs a) {
 // grid (ceil(E/64), n): dfh[v][e] = scale * sum_k dz[v][k] t[k][e]
 __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* __restrict__ dz) {
     extern __shared__ float sm[];
-    __shared__ float part[4][HO];
+    __shared__ float part[NS][HO];
     const int v = blockIdx.y, e = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < a.K; k += HB) sm[k] = dz[(size_t)v * a.K + k];
     __syncthreads();
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(HB) void head_dfh_kernel(HeadArgs a, const float* _
 __global__ __launch_bounds__(HB) void head_dy_kernel(HeadArgs a) {
     extern __shared__ float sm[];
     __shared__ float red[HB / 64];
-    __shared__ float part[4][HO];
+    __shared__ float part[NS][HO];
     const int v = blockIdx.y, d = blockIdx.x * HO + (threadIdx.x & (HO - 1)), slice = threadIdx.x >> 6;
     const float* f = a.f + (size_t)v * a.E;
     const float* dfh = a.tmp_e + (size_t)v * a.E;
