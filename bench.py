@@ -40,17 +40,25 @@ def parse_args():
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
     ap.add_argument("--streams", type=int, default=3, help="independent episodes in flight per GPU (HIP streams)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="MFMA operand dtype")
+    ap.add_argument("--precision", default="auto", choices=["auto", "bf16", "fp16"],
+                    help="MFMA operand dtype.  auto (default): BOTH builds are timed under one protocol (same steps / warm-up / repeats / "
+                         "graph regime, blocks interleaved) and the headline is the build that meets the north_star's tolerance on the "
+                         "reference-generated fixture (selection mask exact, logits within 1e-3): fp16 operands, the reference's own "
+                         "autocast dtype (ttl.py:79); the other build is reported under its own key.  bf16 / fp16: that build only")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay every episode as one HIP graph launch; 0: plain enqueues; -1 (default): graphs when more than one "
-                         "rank shares the host or when the warm-up shows the enqueue loop taking > 50 %% of a step")
-    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps images each; value = the median block")
+                         "rank shares the host or when the warm-up shows the enqueue loop taking > 50 %% of a step; decided ONCE for all legs")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps images each; value = the median block.  When a block "
+                    "is shorter than 0.25 s the count is raised until the timed blocks cover 1.5 s (at most 25)")
     ap.add_argument("--lora-targets", default="qv", help="projections that carry an adapter: qv (the reference's LoraConfig, "
                     "clip/custom_clip.py:586), qkvo (BASELINE.json north_star), or a comma list of q_proj,k_proj,v_proj,out_proj")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores of its GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity check against the reference-generated fixture")
-    ap.add_argument("--no-fp16-leg", action="store_true", help="skip the second timed leg on the fp16-operand build")
+    ap.add_argument("--variant-lib", action="store_true", help="allow TTL_HIP_LIB_BF16 / TTL_HIP_LIB_FP16 to swap in another build of the "
+                    "library (A/B tools); without it such an override is refused, and the line always records path + sha256 of what ran")
+    ap.add_argument("--strict-balance", action="store_true", help="N > 1: exit non-zero when the slowest rank is > 10 %% under the median "
+                    "rank (the line carries rank_balance either way)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for smoke-testing the N>1 logic on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="smoke test: put every rank on cuda:0 (with --backend gloo)")
@@ -170,7 +178,7 @@ def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
 
 def parity_check(precision):
     """Untimed: the reference-generated fixture b16_n64_k200_ent0 (ViT-B/16, 64 views, K=200: the benched workload's
-    shape) through the benched build.  metric = max|a-b| / max|b| per tensor (tests/helpers.max_rel)."""
+    shape) through the build for `precision`.  metric = max|a-b| / max|b| per tensor (tests/helpers.max_rel)."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -193,23 +201,36 @@ def parity_check(precision):
     grads, off, gerr, werr, wfar, wn = eng.grads.cpu().numpy(), 0, 0.0, 0.0, 0, 0
     new = flat.cpu().numpy()
     tol = 1e-3
+    # norm-wise figures beside the element-wise ones (SURVEY 7.2 "relative Frobenius norm"): ||a-b||_F / ||b||_F over ALL the
+    # trainable tensors; for the post-step weights both of the weights themselves and of the UPDATE (new - initial), which is
+    # what the step produced (B starts at 0, so for B the two coincide; A moves by lr*wd only, Q11)
+    dn2 = rn2 = du2 = ru2 = dg2 = rg2 = 0.0
     for k in names:
         n = lora0[k].size
         gref = g["grad/" + k]
+        gnew = grads[off:off + n].reshape(gref.shape).astype(np.float64)
         if np.abs(gref).max() > 0:
-            gerr = max(gerr, max_rel(grads[off:off + n].reshape(gref.shape), gref))
-        d = np.abs(new[off:off + n].reshape(gref.shape) - g["lora1/" + k])
+            gerr = max(gerr, max_rel(gnew, gref))
+        dg2 += float(((gnew - gref) ** 2).sum()); rg2 += float((np.asarray(gref, np.float64) ** 2).sum())
+        wnew, wref, w0 = new[off:off + n].reshape(gref.shape).astype(np.float64), np.asarray(g["lora1/" + k], np.float64), np.asarray(lora0[k], np.float64)
+        d = np.abs(wnew - wref)
+        dn2 += float((d ** 2).sum()); rn2 += float((wref ** 2).sum())
+        du2 += float((d ** 2).sum()); ru2 += float(((wref - w0) ** 2).sum())
         werr = max(werr, float(d.max()))
-        wfar += int((d > tol * np.abs(g["lora1/" + k]).max()).sum())
+        wfar += int((d > tol * np.abs(wref).max()).sum())
         wn += n
         off += n
     le, ae = max_rel(l0.cpu().numpy(), g["logits0"]), max_rel(l1.cpu().numpy(), g["logits1"])
     mask = bool(np.array_equal(np.sort(idx), np.sort(np.asarray(g["idx"]).reshape(-1))))
+    wfro = (dn2 / max(rn2, 1e-300)) ** 0.5
     out = {"fixture": "tests/golden/b16_n64_k200_ent0.npz (written by the reference's own test_time_tuning, fp32 CPU)",
            "dtype": precision, "metric": "max|a-b|/max|b| per tensor",
            "logits_max_rel": round(le, 6), "adapted_logits_max_rel": round(ae, 6),
-           "grad_max_rel": round(gerr, 6), "lora_weights_max_abs_diff": round(werr, 8),
+           "grad_max_rel": round(gerr, 6), "grad_rel_frobenius": round((dg2 / max(rg2, 1e-300)) ** 0.5, 6),
+           "lora_weights_max_abs_diff": round(werr, 8),
            "lora_weights_frac_beyond_tolerance": round(wfar / max(wn, 1), 6),
+           "lora_weights_rel_frobenius": round(wfro, 6),
+           "lora_update_rel_frobenius": round((du2 / max(ru2, 1e-300)) ** 0.5, 6),
            "mask_exact": mask, "top1_equal": bool(int(l1.argmax()) == int(g["top5"][0, 0])),
            "north_star_tolerance": tol,
            # BASELINE.json north_star, item by item: selection mask bit-exact, logits within 1e-3, LoRA weights within 1e-3.
@@ -217,9 +238,12 @@ def parity_check(precision):
            # -lr*g/(|g|+eps)), so an element whose gradient is smaller than the gradient deviation lands 2*lr away whatever
            # the implementation; the gradient deviation itself is set by the 16-bit FORWARD (an exact fp32 backward after the
            # same fp16 forward sits at 2.9e-3 on this fixture: profiles/r03_fp16_grad_points.txt), i.e. it is a property of
-           # 16-bit operands — the reference's own autocast path included — not of this backward.
+           # 16-bit operands — the reference's own autocast path included — not of this backward.  lora_weights is judged
+           # element-wise (max) AND norm-wise (relative Frobenius): `lora_weights` is the element-wise verdict,
+           # `lora_weights_frobenius` the norm-wise one.
            "meets_north_star_tolerance": {"selection_mask": mask, "logits": bool(le <= tol and ae <= tol),
                                           "lora_weights": bool(werr <= tol * max(float(np.abs(g["lora1/" + k]).max()) for k in names)),
+                                          "lora_weights_frobenius": bool(wfro <= tol),
                                           "lora_gradients": bool(gerr <= tol),
                                           "all": bool(mask and le <= tol and ae <= tol and gerr <= tol)}}
     eng.close()
@@ -234,8 +258,31 @@ def parse_targets(spec):
     return tuple(t.strip() for t in spec.split(",") if t.strip())
 
 
+def lib_identity(precision):
+    """Which shared library a leg really ran: path (relative to the repo) + sha256[:16] of the file."""
+    import hashlib
+    from ttl_amd import _lib
+    path = _lib.LIB_PATHS[precision]
+    with open(path, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"lib_path": os.path.relpath(path, ROOT), "lib_sha256_16": sha}
+
+
+def spread(vals):
+    """(median, min, max, inter-quartile range) of a list; quartiles by linear interpolation."""
+    import statistics
+    v = sorted(vals)
+    if len(v) < 2:
+        return v[0], v[0], v[0], 0.0
+    q = statistics.quantiles(v, n=4, method="inclusive")
+    return statistics.median(v), v[0], v[-1], q[2] - q[0]
+
+
 def main():
     a = parse_args()
+    overrides = sorted(k for k in os.environ if k.startswith("TTL_HIP_LIB_") and os.environ[k])
+    if overrides and not a.variant_lib:
+        raise SystemExit(f"{', '.join(overrides)} would swap the library under the bench: pass --variant-lib if that is intended")
     self_spawn(a)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -246,7 +293,6 @@ def main():
     if not a.no_pin:
         from ttl_amd.driver import pin_to_gpu_numa_node
         pin = pin_to_gpu_numa_node(0 if a.same_device else local, n_local_ranks=world)
-    import statistics
     import torch
     import torch.distributed as dist
 
@@ -291,53 +337,114 @@ def main():
     labels = [torch.tensor([(7 * j) % a.classes], device=dev) for j in range(a.pool)]
     item = lambda i: ((i * 2654435761) >> 16) % a.pool
 
+    # the legs: BOTH operand builds under one protocol (auto), or the one asked for.  The conforming build comes first.
+    legs = ["fp16", "bf16"] if a.precision == "auto" else [a.precision]
+    ident = {p: lib_identity(p) for p in legs}
+
+    # ---- untimed parity of every leg against the reference-generated fixture (rank 0; decides the headline in auto mode)
+    parity = {}
+    if rank == 0 and not a.no_parity and cfg.name == "ViT-B/16":
+        for p in legs:
+            try:
+                parity[p] = parity_check(p)
+            except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
+                parity[p] = {"error": f"{type(e).__name__}: {e}"}
+
+    def conforms(p):
+        m = parity.get(p, {}).get("meets_north_star_tolerance")
+        return bool(m and m["selection_mask"] and m["logits"])
+
     def fence(pipe):
+        """-> seconds until THIS rank's streams were drained (before the barrier the other ranks join)"""
+        t = time.perf_counter()
         pipe.synchronize()
         torch.cuda.synchronize()
+        t_local = time.perf_counter() - t
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+        return t_local
 
     def block(pipe, n_items):
-        """one timed block: this rank's items of a stream of world * n_items -> (wall s, max over ranks; s spent in submit())"""
+        """one timed block: this rank's items of a stream of world * n_items
+        -> (wall s incl. the closing barrier, max over ranks; s spent in submit(); s until this rank alone had finished)"""
         t0 = time.perf_counter()
         for i in shard.indices(world * n_items):
             pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, n_updates=a.updates)
         t_enq = time.perf_counter() - t0
-        fence(pipe)
+        t_local = t_enq + fence(pipe)
         dt = time.perf_counter() - t0
-        return float(shard.max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()), t_enq
+        return float(shard.max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()), t_enq, t_local
 
-    def timed_run(precision, steps, warmup, repeats, graph):
-        """W warm-up steps, then `repeats` blocks of EXACTLY `steps` steps per rank, each bracketed by barrier + synchronize on
-        both sides and taken as the max over ranks; the block with the median time is the one reported."""
-        use_graph = (world > 1) if graph < 0 else bool(graph)
-        why = "--graph" if graph >= 0 else ("auto: %d ranks share the host" % world if world > 1 else "auto: off")
-        pipe = EpisodePipeline(cfg, weights, names, lora, tfeat, 100.0, dev, n_streams=a.streams, max_views=a.views,
+    def make_pipe(precision, use_graph):
+        return EpisodePipeline(cfg, weights, names, lora, tfeat, 100.0, dev, n_streams=a.streams, max_views=a.views,
                                precision=precision, use_graph=use_graph)
-        fence(pipe)
-        Tw, enq = block(pipe, warmup)
-        if graph < 0 and not use_graph and warmup > 0 and enq / max(Tw, 1e-9) > 0.5:
-            # the enqueue loop is more than half of a step: the host would bound the run as soon as anything else shares its
-            # cores -> replay each episode as ONE graph launch (bit-identical results, tests/test_gpu_path.py)
-            pipe.close()
-            use_graph, why = True, f"auto: enqueue loop took {enq / Tw:.0%} of the warm-up's wall time"
-            pipe = EpisodePipeline(cfg, weights, names, lora, tfeat, 100.0, dev, n_streams=a.streams, max_views=a.views,
-                                   precision=precision, use_graph=True)
-            fence(pipe)
-            block(pipe, warmup)
-        blocks = []
-        for r in range(max(repeats, 1)):
-            pipe.reset_totals()
-            fence(pipe)
-            blocks.append(block(pipe, steps))
-        order = sorted(range(len(blocks)), key=lambda j: blocks[j][0])
-        med = order[len(order) // 2]
-        return pipe, dict(T=blocks[med][0], enqueue_s=blocks[med][1], all_T=[b[0] for b in blocks], hip_graph=use_graph, hip_graph_reason=why)
 
-    pipe, run = timed_run(a.precision, a.steps, a.warmup, a.repeats, a.graph)
-    T = run["T"]
-    acc = shard.accuracy(pipe.totals())                       # C1: accuracy accumulator of the LAST timed block (the path's only collective)
+    # ---- ONE protocol for all legs: the graph regime is decided once, after a warm-up that has exercised every library
+    use_graph = (world > 1) if a.graph < 0 else bool(a.graph)
+    why = "--graph" if a.graph >= 0 else ("auto: %d ranks share the host" % world if world > 1 else "auto: off")
+    pipes, warm = {}, {}
+    for p in legs:
+        pipes[p] = make_pipe(p, use_graph)
+        fence(pipes[p])
+        warm[p] = block(pipes[p], a.warmup)
+    if a.graph < 0 and not use_graph and a.warmup > 0:
+        share = max(warm[p][1] / max(warm[p][0], 1e-9) for p in legs)
+        if share > 0.5:
+            # the enqueue loop is more than half of a step: the host would bound the run as soon as anything else shares its
+            # cores -> replay each episode as ONE graph launch (bit-identical results, tests/test_gpu_path.py), for EVERY leg
+            use_graph, why = True, f"auto: enqueue loop took {share:.0%} of the warm-up's wall time"
+            for p in legs:
+                pipes[p].close()
+            for p in legs:
+                pipes[p] = make_pipe(p, True)
+                fence(pipes[p])
+                block(pipes[p], a.warmup)
+    # timed blocks, interleaved over the legs (leg A block, leg B block, ...): both builds see the same clocks and thermals.
+    # Blocks shorter than 0.25 s: more of them, until the timed blocks of a leg cover 1.5 s (the decision is taken from the
+    # max-over-ranks time of the first block, so every rank takes it alike)
+    blocks = {p: [] for p in legs}
+    repeats = max(a.repeats, 1)
+    r = 0
+    while r < repeats:
+        for p in legs:
+            pipes[p].reset_totals()
+            fence(pipes[p])
+            blocks[p].append(block(pipes[p], a.steps))
+        if r == 0:
+            t_first = max(blocks[p][0][0] for p in legs)
+            if t_first < 0.25:
+                repeats = min(25, max(repeats, int(1.5 / max(t_first, 1e-4)) + 1))
+        r += 1
+
+    def leg_numbers(p):
+        T = [b[0] for b in blocks[p]]
+        order = sorted(range(len(T)), key=lambda j: T[j])
+        med = order[len(order) // 2]
+        vals = [world * a.steps / t for t in T]
+        _, vmin, vmax, iqr = spread(vals)
+        out = {"value": round(world * a.steps / T[med], 2), "unit": "images/sec", "ms_per_step": round(1e3 * T[med] / a.steps, 4),
+               "steps": a.steps, "warmup": a.warmup, "repeats": len(T), "value_min": round(vmin, 2), "value_max": round(vmax, 2),
+               "value_iqr": round(iqr, 2), "host_enqueue_ms_per_image": round(1e3 * blocks[p][med][1] / a.steps, 4),
+               "hip_graph": use_graph, "dtype": p}
+        out.update(ident[p])
+        if world > 1:
+            # every rank's own rate (steps / time until ITS streams were drained, before the barrier), median over its blocks
+            mine = sorted(a.steps / b[2] for b in blocks[p])[len(T) // 2]
+            per_rank = shard.gather(torch.tensor([mine], dtype=torch.float64, device=dev)).reshape(-1).tolist()
+            med_rank = sorted(per_rank)[len(per_rank) // 2]
+            out["per_rank_value"] = [round(v, 2) for v in per_rank]
+            out["rank_balance"] = {"slowest_over_median": round(min(per_rank) / med_rank, 4), "ok": bool(min(per_rank) >= 0.9 * med_rank),
+                                   "note": "per-rank images/sec before the closing barrier; not ok = the slowest rank is more than 10 % "
+                                           "under the median rank (NUMA placement, a busy GPU, clocks): look at it before reading `value`"}
+        return out
+
+    numbers = {p: leg_numbers(p) for p in legs}
+    acc = {p: shard.accuracy(pipes[p].totals()) for p in legs}   # C1: accuracy accumulator of the LAST timed block (the path's only collective)
+    graph_per_rank = None
+    if world > 1:
+        graph_per_rank = [bool(v) for v in shard.gather(torch.tensor([float(all(pipes[p].use_graph for p in legs))], dtype=torch.float64,
+                                                                     device=dev)).reshape(-1).tolist()]
 
     def roofline_of(pipe):
         """HIP events on the launch streams around every launch group (ttl_profile_*): pass A in the timed region's regime
@@ -399,9 +506,11 @@ def main():
                                        "class_ms_per_image": {k: round(val / nprof, 3) for k, val in ms.items()}}}
         return roof, executed
 
-    roof = executed = None
+    roofs, executed = {}, None
     if rank == 0:
-        roof, executed = roofline_of(pipe)
+        for p in legs:
+            roofs[p], ex = roofline_of(pipes[p])
+            executed = ex if executed is None else executed
         # HBM-side traffic of the same launches: PMC passes cannot run inside this process, so the figure is STATIC: read
         # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this command (tools/pmc_traffic.py)
         import glob
@@ -409,76 +518,91 @@ def main():
         if cand and a.arch == "ViT-B/16" and a.views == 64 and a.classes == 200 and a.rank == 16 and a.updates == 1 and a.lora_targets == "qv":
             try:
                 tj = json.load(open(cand[-1]))
-                roof["traffic"] = tj["traffic_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/" + os.path.basename(cand[-1])
-                roof["traffic_regime"] = "static: " + tj.get("regime", "rocprofv3 --pmc, streams=1, separate FETCH_SIZE / WRITE_SIZE passes")
+                for p in legs:
+                    roofs[p]["traffic"] = tj["traffic_bytes_per_launch"]
+                    roofs[p]["traffic_source"] = "profiles/" + os.path.basename(cand[-1])
+                    roofs[p]["traffic_regime"] = "static (bf16 build; the fp16 build moves the same bytes): " + tj.get(
+                        "regime", "rocprofv3 --pmc, streams=1, separate FETCH_SIZE / WRITE_SIZE passes")
             except Exception:
                 pass
-    pipe.close()
-
-    # ---- second timed leg on the fp16-operand build (the one that meets the 1e-3 parity tolerance), same process, same protocol
-    fp16_leg = None
-    if a.precision == "bf16" and not a.no_fp16_leg and world == 1:
-        n16 = max(a.steps // 2, 10)
-        pipe16, run16 = timed_run("fp16", n16, max(a.warmup // 2, 5), max(a.repeats, 1), a.graph)
-        roof16, _ = roofline_of(pipe16)
-        fp16_leg = {"value": round(world * n16 / run16["T"], 2), "unit": "images/sec", "ms_per_step": round(1e3 * run16["T"] / n16, 4),
-                    "steps": n16, "repeats": len(run16["all_T"]),
-                    "value_min": round(world * n16 / max(run16["all_T"]), 2), "value_max": round(world * n16 / min(run16["all_T"]), 2),
-                    "hip_graph": run16["hip_graph"],
-                    "roofline": {k: roof16[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_image",
-                                                        "class_ms_per_image", "regime")},
-                    "note": "libttl_hip_fp16.so: IEEE-half MFMA operands (the reference's autocast dtype, ttl.py:79), same kernels "
-                            "(identical instruction streams but for the convert opcodes), same MFMA rate; the build that is judged "
-                            "against the 1e-3 tolerance (parity_fp16)"}
-        pipe16.close()
+    for p in legs:
+        pipes[p].close()
 
     if rank == 0:
-        value = world * a.steps / T
+        # headline: the first leg (fp16 before bf16) whose parity verdict meets mask + logits; without a verdict, the first leg
+        head = next((p for p in legs if conforms(p)), legs[0])
+        n = numbers[head]
+        value = n["value"]
         flops = episode_flops(cfg, a.views, a.classes) * a.updates  # (1-view inference counted once per update: <2%)
         tg = "+".join(t.split("_")[0] for t in targets)
+        rccl = None
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        notes = {"fp16": "IEEE-half MFMA operands, fp32 accumulate / residual stream / LayerNorm / softmax / head / loss / optimizer: the "
+                         "reference's own GPU arithmetic (torch.cuda.amp.autocast(), ttl.py:79, with GradScaler(init_scale=1000), ttl.py:222); "
+                         "same dense MFMA peak as bf16",
+                 "bf16": "bf16 MFMA operands (the dtype BASELINE.json's north_star names for the GEMMs), fp32 everything else; "
+                         "logits sit 3-5e-3 from the reference's fp32 path, outside the north_star's own 1e-3"}
         out = {
             "metric": "test images/sec (64-view TTA, 1 step), CLIP ViT-B/16 r=16",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * T / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "repeats": len(run["all_T"]), "value_min": round(world * a.steps / max(run["all_T"]), 2),
-            "value_max": round(world * a.steps / min(run["all_T"]), 2),
+            "value": value, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": n["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": head, "dtype_note": notes[head], "data": "synthetic",
+            "headline_rule": "the first of [fp16, bf16] operand builds whose measured parity (`parity`) meets the north_star's selection-mask "
+                             "and logit tolerance; every build timed is listed under `legs`, all under ONE protocol (`protocol`)",
+            "value_conforming": value if conforms(head) else None, "dtype_conforming": head if conforms(head) else None,
+            "repeats": n["repeats"], "value_min": n["value_min"], "value_max": n["value_max"], "value_iqr": n["value_iqr"],
             "value_note": "median of `repeats` timed blocks of `steps` steps per rank each (every block: barrier + synchronize on both "
-                          "sides, max over ranks)",
-            "host_enqueue_ms_per_image": round(1e3 * run["enqueue_s"] / a.steps, 4),
+                          "sides, max over ranks); blocks of the legs interleaved",
+            "host_enqueue_ms_per_image": n["host_enqueue_ms_per_image"],
+            "lib_path": n["lib_path"], "lib_sha256_16": n["lib_sha256_16"],
+            "protocol": {"steps": a.steps, "warmup": a.warmup, "repeats": n["repeats"], "hip_graph": use_graph, "hip_graph_reason": why,
+                         "legs": legs, "interleaved_blocks": len(legs) > 1, "variant_lib_env": overrides},
             "config": {"workload": f"{cfg.name} r={cfg.rank}, adapters on {tg}, {a.views} views, {a.updates} TTA step, K={a.classes} "
                                    f"(ImageNet-A shape), layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
                                    f"1-view inference; views pre-staged in HBM; {a.steps} images/rank per timed block",
                        "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates,
-                       "lora_targets": list(targets), "streams_per_gpu": a.streams, "hip_graph": run["hip_graph"],
-                       "hip_graph_reason": run["hip_graph_reason"], "cpu_pinning": pin,
+                       "lora_targets": list(targets), "streams_per_gpu": a.streams, "hip_graph": use_graph,
+                       "hip_graph_reason": why, "hip_graph_per_rank": graph_per_rank, "cpu_pinning": pin, "rccl_version": rccl,
+                       "backend": a.backend if world > 1 else None,
                        "parallelism": f"image-sharded x{world} (item i -> rank i % {world}), {a.streams} episodes in flight per GPU"},
             "tflop_per_image": round(flops / 1e12, 3),
             "tflop_per_image_executed": None if executed is None else round(executed / 1e12, 3),
             "whole_path_tflops_per_gpu": round(flops * value / world / 1e12, 1),
             "whole_path_frac_of_bf16_peak": round(flops * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
             "whole_path_frac_executed": None if executed is None else round(executed * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "accuracy_accumulator": {"top1_hits": acc["hits1"], "top5_hits": acc["hits5"], "images": acc["count"],
+            "accuracy_accumulator": {"top1_hits": acc[head]["hits1"], "top5_hits": acc[head]["hits5"], "images": acc[head]["count"],
                                      "note": "synthetic labels: exercises the sharded accumulator + all-reduce, not a quality number; "
                                              "no pretrained checkpoint / dataset exists offline, so README top-1 is not reproducible here"},
-            "roofline": roof,
+            "roofline": roofs.get(head),
         }
-        if fp16_leg:
-            out["fp16"] = fp16_leg
-        if not a.no_parity and cfg.name == "ViT-B/16":
-            try:
-                out["parity"] = parity_check(a.precision)
-                if a.precision == "bf16" and not a.no_fp16_leg:
-                    out["parity_fp16"] = parity_check("fp16")
-            except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
-                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            out["per_rank_value"] = n["per_rank_value"]
+            out["rank_balance"] = n["rank_balance"]
+        if head in parity:
+            out["parity"] = parity[head]
+        out["legs"] = {}
+        for p in legs:
+            leg = dict(numbers[p])
+            leg["is_headline"] = (p == head)
+            leg["note"] = notes[p]
+            leg["whole_path_frac_of_bf16_peak"] = round(flops * leg["value"] / world / 1e12 / PEAK_BF16_TFLOPS, 4)
+            if p in roofs:
+                leg["roofline"] = roofs[p]
+            if p in parity:
+                leg["parity"] = parity[p]
+            out["legs"][p] = leg
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.classes, a.views)
         print(json.dumps(out), flush=True)
+    bad_balance = world > 1 and any(not numbers[p]["rank_balance"]["ok"] for p in legs)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if bad_balance and a.strict_balance:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

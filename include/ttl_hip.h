@@ -82,7 +82,8 @@ void ttl_ctx_destroy(ttl_ctx* ctx);
  * weights (not itself shared), have them all loaded (ttl_weights_ready), have the same model configuration as `cfg`
  * (max_views / max_classes may differ).  The parent's memory is reference-counted: it is released when the parent AND every context
  * sharing its images have been destroyed, in whatever order (a destroyed parent must still not be USED).  ttl_load_weight on the new
- * context is an error. */
+ * context is an error, and sharing FREEZES the parent's weights: ttl_load_weight on the parent fails with TTL_ESTATE while any
+ * sharer is alive.  (ttl_workspace_bytes(cfg) is the footprint of an OWNING context; a sharing one allocates less.) */
 int ttl_ctx_create_shared(const ttl_config* cfg, ttl_ctx* parent, ttl_ctx** out);
 
 /* Load one fp32 tensor of the HF vision tower by its state-dict name,

@@ -124,6 +124,8 @@ def install_import_stubs():
 
 
 TARGET_MODULES_OVERRIDE = None
+# synth.vision_weights variant the patched CLIPModel.from_pretrained loads (None, or "outliers": CLIP-like activation statistics)
+WEIGHTS_VARIANT = None
 
 
 def make_clip_model(cfg, seed, text_seed=1234, text_cfg=None):
@@ -149,7 +151,7 @@ def make_clip_model(cfg, seed, text_seed=1234, text_cfg=None):
             projection_dim=cfg.embed)
         conf._attn_implementation = "eager"
         model = CLIPModel(conf).float().eval()
-        W = dict(synth.vision_weights(cfg, seed))
+        W = dict(synth.vision_weights(cfg, seed, variant=WEIGHTS_VARIANT))
         W.update(synth.text_weights(text_cfg, seed))
         sd = model.state_dict()
         for k, a in W.items():
@@ -175,7 +177,7 @@ def make_clip_model(cfg, seed, text_seed=1234, text_cfg=None):
         projection_dim=cfg.embed)
     conf._attn_implementation = "eager"
     model = CLIPModel(conf).float().eval()
-    W = synth.vision_weights(cfg, seed)
+    W = synth.vision_weights(cfg, seed, variant=WEIGHTS_VARIANT)
     sd = model.state_dict()
     for k, a in W.items():
         assert k in sd and tuple(sd[k].shape) == a.shape, (k, a.shape)

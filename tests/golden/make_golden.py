@@ -67,6 +67,17 @@ CASES = {
     # reference's init, so that dA == 0 and the K-extension columns are idle) are set to seeded N(0, 0.02^2) values by the
     # harness AFTER the reference's LoRA_reset and BEFORE its test_time_tuning — input state, the reference's code is untouched
     "b16_n8_k10_qkvo": ("ViT-B/16", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "lora_B_std": 0.02}),
+    # a multi-update episode with adapters on all four projections and NON-ZERO B from the start: every gradient (k_proj's included,
+    # which is fp32 noise while B == 0) is a real signal in every update, so the oracle is pinned tightly through the resumed forward
+    # and the multi-step backward of the q/k/v/out path (round-3 advisor; tiny_qkvo_steps2 can only be compared loosely)
+    "tiny_qkvo_steps2_b": ("tiny", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "tta_steps": 2, "lora_B_std": 0.05}),
+    # CLIP-like activation statistics (synth.add_activation_outliers: a few residual channels 30-100x the rest on the CLS / one patch
+    # token / every token, LayerNorm gains far from 1 on them) — what the checkpoint the reference loads (clip/custom_clip.py:581) is
+    # known for and Gaussian weights do not show; every other fixture is pinned on Gaussian weights
+    "b16_n8_k10_outliers": ("ViT-B/16", 8, 10, {"weights_variant": "outliers"}),
+    "b16_n64_k200_outliers": ("ViT-B/16", 64, 200, {"weights_variant": "outliers"}),
+    "b16_n64_k200_outliers_ent1": ("ViT-B/16", 64, 200, {"weights_variant": "outliers", "filter_ent": 1}),
+    "tiny_outliers": ("tiny", 8, 10, {"weights_variant": "outliers"}),
 }
 
 
@@ -92,6 +103,7 @@ def build_reference(case):
     over = dict(over)
     targets = over.pop("target_modules", None)
     H.TARGET_MODULES_OVERRIDE = targets
+    H.WEIGHTS_VARIANT = over.pop("weights_variant", None)
     if targets:
         cfg = cfg.replace(lora_targets=tuple(targets))
     args = default_args(**over)
@@ -214,7 +226,7 @@ def run_case(case):
     trained = [k for k in lora0 if any(f"layers.{i}." in k for i in range(cfg.layer_lo, cfg.layer_hi + 1))]
     out = dict(
         arch=cfg.name, rank=cfg.rank, lora_targets=np.array(list(cfg.lora_targets)), n_views=N, n_classes=K, weight_seed=0, view_seed=7,
-        weights_sha256=synth.checksum(synth.vision_weights(cfg, 0)),
+        weights_sha256=synth.checksum(synth.vision_weights(cfg, 0, variant=H.WEIGHTS_VARIANT)),
         x_sha256=synth.checksum([x.numpy()]),
         objective="deyo" if args.deyo_selection else "tpt",
         mode="topk" if (args.filter_ent or not args.deyo_selection) else "le_thresh",
@@ -224,6 +236,8 @@ def run_case(case):
         logits_last=rec["logits"][n_fwd - 2 - (1 if args.filter_plpd else 0)].numpy(),
         logits1=out1.numpy(), top5=torch.topk(out1, min(5, K), dim=1).indices.numpy())
     out.update(extra)
+    if H.WEIGHTS_VARIANT:
+        out["weights_variant"] = H.WEIGHTS_VARIANT
     for k in (lora0 if cfg.width <= 128 else trained):
         out["lora0/" + k] = lora0[k]
     for k in trained:

@@ -15,7 +15,8 @@ def load_case(name):
     cfg = get_config(str(g["arch"])).replace(rank=int(g["rank"]))
     if "lora_targets" in g.files:          # fixtures with adapters beyond the reference's q_proj / v_proj
         cfg = cfg.replace(lora_targets=tuple(str(t) for t in g["lora_targets"]))
-    W = synth.vision_weights(cfg, int(g["weight_seed"]))
+    variant = str(g["weights_variant"]) if "weights_variant" in g.files else None      # "outliers": CLIP-like activation statistics
+    W = synth.vision_weights(cfg, int(g["weight_seed"]), variant=variant)
     assert synth.checksum(W) == str(g["weights_sha256"]), "synthetic weights drifted from the fixture"
     x = synth.views(cfg, int(g["n_views"]), int(g["view_seed"]))
     assert synth.checksum([x]) == str(g["x_sha256"]), "synthetic views drifted from the fixture"

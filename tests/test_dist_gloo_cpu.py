@@ -90,3 +90,125 @@ def test_view_boxes_depend_on_seed_and_global_index_only():
     assert not torch.equal(whole[0], whole[1])
     assert not torch.equal(GpuAugMixAugmenter(n_views=7, seed=12).boxes(375, 500, 0), whole[0])
     assert all(int(b[0, 4]) == 2 for b in whole)                               # view 0 stays the base view
+
+
+# ---- 8 ranks on one host: every rank finds ITS GPU's NUMA node from a fixture sysfs tree (no KFD: the drm / PCI-order fallback)
+PCI = ["0000:05:00.0", "0000:15:00.0", "0000:65:00.0", "0000:75:00.0", "0000:85:00.0", "0000:95:00.0", "0000:e5:00.0", "0000:f5:00.0"]
+NODE_OF = [3, 2, 1, 0, 7, 6, 5, 4]            # GPU i (PCI order) hangs off NUMA node NODE_OF[i] (NPS4 x 2 sockets, scrambled)
+
+
+def make_fixture_sysfs(root, with_kfd=False):
+    """An 8-GPU, 8-NUMA-node /sys: devices/pci.../<addr>/{vendor,class,numa_node}, class/drm/card<k> and renderD<128+k> symlinked to
+    them (card numbers deliberately NOT in PCI order), devices/system/node/node<n>/cpulist = 16 CPUs each; plus two non-GPU cards."""
+    import os
+    for i, addr in enumerate(PCI):
+        d = os.path.join(root, "devices/pci0000:00", addr)
+        os.makedirs(d)
+        for name, val in (("vendor", "0x1002"), ("class", "0x120000"), ("numa_node", str(NODE_OF[i]))):
+            with open(os.path.join(d, name), "w") as f:
+                f.write(val + "\n")
+    extra = {"0000:01:00.0": ("0x1a03", "0x030000", "0"), "0000:02:00.0": ("0x1002", "0x040300", "0")}   # BMC VGA; an AMD audio function
+    for addr, (ven, cls, node) in extra.items():
+        d = os.path.join(root, "devices/pci0000:00", addr)
+        os.makedirs(d)
+        for name, val in (("vendor", ven), ("class", cls), ("numa_node", node)):
+            with open(os.path.join(d, name), "w") as f:
+                f.write(val + "\n")
+    drm = os.path.join(root, "class/drm")
+    os.makedirs(drm)
+    order = [0, 5, 2, 7, 4, 1, 6, 3]              # card k+1 -> GPU order[k]
+    os.makedirs(os.path.join(drm, "card0"))
+    os.symlink(os.path.join(root, "devices/pci0000:00", "0000:01:00.0"), os.path.join(drm, "card0", "device"))
+    os.makedirs(os.path.join(drm, "card0-VGA-1"))
+    for k, g in enumerate(order):
+        for nm in (f"card{k + 1}", f"renderD{128 + k}"):
+            os.makedirs(os.path.join(drm, nm))
+            os.symlink(os.path.join(root, "devices/pci0000:00", PCI[g]), os.path.join(drm, nm, "device"))
+    os.makedirs(os.path.join(drm, "card9"))
+    os.symlink(os.path.join(root, "devices/pci0000:00", "0000:02:00.0"), os.path.join(drm, "card9", "device"))
+    for n in range(8):
+        d = os.path.join(root, f"devices/system/node/node{n}")
+        os.makedirs(d)
+        with open(os.path.join(d, "cpulist"), "w") as f:
+            f.write(f"{16 * n}-{16 * n + 7},{128 + 16 * n}-{128 + 16 * n + 7}\n")
+    if with_kfd:                                   # KFD lists the GPUs in PCI order too, behind two CPU nodes
+        base = os.path.join(root, "class/kfd/kfd/topology/nodes")
+        for n in range(2):
+            os.makedirs(os.path.join(base, str(n)))
+            with open(os.path.join(base, str(n), "properties"), "w") as f:
+                f.write("simd_count 0\ndrm_render_minor 0\n")
+        for g in range(8):
+            os.makedirs(os.path.join(base, str(2 + g)))
+            with open(os.path.join(base, str(2 + g), "properties"), "w") as f:
+                f.write(f"simd_count 1024\ndrm_render_minor {128 + order.index(g)}\n")
+    return root
+
+
+def _numa_worker(rank, world, port, sysfs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ttl_amd.driver import gpu_numa_cpus, pin_to_gpu_numa_node
+    node, cpus, src = gpu_numa_cpus(rank, sysfs, env={}, with_source=True)        # BEFORE the process group, like bench.py does
+    rec = pin_to_gpu_numa_node(rank, world, sysfs, env={}, apply=False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = ImageShard(rank, world)
+    nodes = shard.gather(torch.tensor([float(node), float(min(cpus))], dtype=torch.float64))
+    q.put((rank, dict(node=node, src=src, first_cpu=min(cpus), n_cpus=len(cpus), rec=rec, all_nodes=nodes[:, 0].tolist(),
+                      all_first=nodes[:, 1].tolist(), seen=shard.ranks_seen())))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_pick_eight_distinct_numa_nodes_without_kfd(tmp_path):
+    """one process per GPU, 8 per node.  On a box whose container hides /sys/class/kfd (the driver's own bench box did)
+    the rank -> NUMA node map comes from /sys/class/drm/card*/device ordered by PCI address; 8 gloo ranks each resolve their own
+    GPU and the gathered result is 8 distinct nodes / 8 disjoint CPU sets — the map NODE_OF, not card-number order."""
+    sysfs = make_fixture_sysfs(str(tmp_path / "sys"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_numa_worker, args=(r, 8, port, sysfs, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(8):
+        assert res[r]["node"] == NODE_OF[r] and res[r]["src"] == "drm-pci-order" and res[r]["seen"] == 8
+        assert res[r]["first_cpu"] == 16 * NODE_OF[r] and res[r]["n_cpus"] == 16
+        assert res[r]["rec"]["numa_node"] == NODE_OF[r] and res[r]["rec"]["applied"] is False
+        assert res[r]["rec"].get("source") == "drm-pci-order" or "reason" in res[r]["rec"]      # (this container has < 2 of those CPUs)
+        assert res[r]["all_nodes"] == [float(n) for n in NODE_OF]                                # identical on every rank
+    assert len({res[r]["node"] for r in range(8)}) == 8 and len({res[r]["first_cpu"] for r in range(8)}) == 8
+
+
+def test_visible_device_lists_compose_and_unresolvable_ones_do_not_pin(tmp_path):
+    """ROCR_VISIBLE_DEVICES filters the physical list, HIP_ / CUDA_VISIBLE_DEVICES index INTO that subset (round-3 advisor: reading
+    only one of them pins a rank to another GPU's socket while the record says applied).  UUID entries, out-of-range indices or
+    HIP / CUDA lists that disagree -> no pin, with the reason in the record.  KFD, when readable, answers before the drm fallback."""
+    from ttl_amd.driver import gpu_numa_cpus, pin_to_gpu_numa_node
+    sysfs = make_fixture_sysfs(str(tmp_path / "sys"), with_kfd=True)
+    node = lambda lr, env: gpu_numa_cpus(lr, sysfs, env=env, with_source=True)
+    assert node(0, {})[0] == NODE_OF[0] and node(0, {})[2] == "kfd"
+    assert node(1, {"ROCR_VISIBLE_DEVICES": "4,5,6,7"})[0] == NODE_OF[5]
+    assert node(0, {"HIP_VISIBLE_DEVICES": "3"})[0] == NODE_OF[3]
+    assert node(0, {"CUDA_VISIBLE_DEVICES": "6,2"})[0] == NODE_OF[6] and node(1, {"CUDA_VISIBLE_DEVICES": "6,2"})[0] == NODE_OF[2]
+    assert node(1, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "2,3"})[0] == NODE_OF[7]       # composed, not either alone
+    assert node(0, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "2,3", "CUDA_VISIBLE_DEVICES": "2,3"})[0] == NODE_OF[6]
+    for env in ({"ROCR_VISIBLE_DEVICES": "GPU-deadbeef00000000"}, {"HIP_VISIBLE_DEVICES": "0,9"}, {"HIP_VISIBLE_DEVICES": "0", "CUDA_VISIBLE_DEVICES": "1"},
+                {"ROCR_VISIBLE_DEVICES": "0,1", "HIP_VISIBLE_DEVICES": "2"}):
+        n, cpus, why = node(0, env)
+        assert n is None and cpus is None and "VISIBLE_DEVICES" in why, (env, why)
+        rec = pin_to_gpu_numa_node(0, 1, sysfs, env=env)
+        assert rec["applied"] is False and rec["numa_node"] is None and "VISIBLE_DEVICES" in rec["reason"]
+    assert node(2, {"HIP_VISIBLE_DEVICES": "0,1"})[0] is None          # more local ranks than visible GPUs
+    # numa_node == -1 everywhere (single-socket VM): nothing to pin to, and the record says which sources were tried
+    for addr in PCI:
+        with open(os.path.join(sysfs, "devices/pci0000:00", addr, "numa_node"), "w") as f:
+            f.write("-1\n")
+    n, cpus, why = node(0, {})
+    assert n is None and "kfd: numa_node -1" in why and "drm-pci-order: numa_node -1" in why
+
+
+def test_gather_is_identity_for_one_rank():
+    t = torch.tensor([1.5, 2.5], dtype=torch.float64)
+    assert torch.equal(ImageShard(0, 1).gather(t), t.reshape(1, 2))

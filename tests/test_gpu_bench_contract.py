@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_line_has_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -30,29 +30,53 @@ def test_bench_json_line_has_the_contract_keys():
     assert r_["bound"] == "mfma" and r_["unit"] == "TFLOP/s" and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-3
     assert d["value"] > 50 and abs(d["ms_per_step"] * d["value"] / 1e3 - 1.0) < 0.02     # value = n_gpus * steps / time
     assert d["ranks_seen"] == 1
-    # measured (not claimed) parity of the benched build against the reference-generated fixture, and the fp16 leg
-    assert d["parity"]["mask_exact"] is True and d["parity"]["top1_equal"] is True and d["parity"]["logits_max_rel"] < 8e-3
-    assert d["parity_fp16"]["logits_max_rel"] < 1e-3 and d["parity_fp16"]["mask_exact"] is True
-    assert d["fp16"]["value"] > 50
+    # ---- ONE protocol for both operand builds; the headline is the build whose MEASURED parity meets the north_star's
+    # selection-mask + logit tolerance (fp16 operands = the reference's autocast dtype, ttl.py:79), named as such
+    assert set(d["legs"]) == {"fp16", "bf16"} and d["protocol"]["legs"] == ["fp16", "bf16"] and d["protocol"]["interleaved_blocks"] is True
+    assert d["dtype"] == "fp16" and d["dtype_conforming"] == "fp16" and d["value_conforming"] == d["value"] and "ttl.py:79" in d["dtype_note"]
+    f16, b16 = d["legs"]["fp16"], d["legs"]["bf16"]
+    assert f16["is_headline"] is True and b16["is_headline"] is False and f16["value"] == d["value"]
+    for leg in (f16, b16):      # same steps, warm-up, repeats and graph regime for every leg
+        assert (leg["steps"], leg["warmup"], leg["repeats"], leg["hip_graph"]) == (6, 2, d["repeats"], d["config"]["hip_graph"])
+        assert leg["value"] > 50 and leg["value_min"] <= leg["value"] <= leg["value_max"] and leg["value_iqr"] >= 0
+        assert leg["lib_path"].endswith(".so") and len(leg["lib_sha256_16"]) == 16
+        rf = leg["roofline"]
+        assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 100
+        assert set(leg["parity"]["meets_north_star_tolerance"]) == {"selection_mask", "logits", "lora_weights", "lora_weights_frobenius",
+                                                                    "lora_gradients", "all"}
+        assert leg["parity"]["mask_exact"] is True and leg["parity"]["top1_equal"] is True
+        for k in ("lora_weights_rel_frobenius", "lora_update_rel_frobenius", "grad_rel_frobenius"):
+            assert 0 <= leg["parity"][k] < 1.0, k
+    assert f16["lib_path"].endswith("libttl_hip_fp16.so") and b16["lib_path"].endswith("libttl_hip.so") and d["lib_path"] == f16["lib_path"]
+    assert d["parity"] == f16["parity"]
+    assert f16["parity"]["meets_north_star_tolerance"]["logits"] is True and f16["parity"]["meets_north_star_tolerance"]["selection_mask"] is True
+    assert f16["parity"]["logits_max_rel"] <= 1e-3 and f16["parity"]["adapted_logits_max_rel"] <= 1e-3
+    assert b16["parity"]["logits_max_rel"] < 6e-3 and b16["parity"]["meets_north_star_tolerance"]["logits"] is False
+    # the conforming build costs at most a few per cent (same kernels, same MFMA rate; the chip holds a lower clock on fp16 operands)
+    assert f16["value"] > 0.93 * b16["value"]
     assert 0 < d["whole_path_frac_executed"] <= d["whole_path_frac_of_bf16_peak"]
-    # the headline is the MEDIAN of `repeats` timed blocks of `steps` steps each; the spread and the host's share are in the line
-    assert d["repeats"] == 5 and d["value_min"] <= d["value"] <= d["value_max"]
+    # the headline is the MEDIAN of `repeats` timed blocks of `steps` steps each; short blocks (6 x 3.5 ms) are repeated until
+    # they cover 1.5 s (at most 25); the spread and the host's share are in the line
+    assert 10 <= d["repeats"] <= 25 and d["value_min"] <= d["value"] <= d["value_max"] and d["value_iqr"] >= 0
     assert 0 < d["host_enqueue_ms_per_image"] < d["ms_per_step"] * 1.05
     assert isinstance(d["config"]["hip_graph"], bool) and d["config"]["lora_targets"] == ["q_proj", "v_proj"]
-    # the tolerance verdict is measured, per build, and the conforming (fp16) build carries its own roofline block
-    for pk in ("parity", "parity_fp16"):
-        assert set(d[pk]["meets_north_star_tolerance"]) == {"selection_mask", "logits", "lora_weights", "lora_gradients", "all"}
-    assert d["parity_fp16"]["meets_north_star_tolerance"]["logits"] is True and d["parity_fp16"]["meets_north_star_tolerance"]["selection_mask"] is True
-    assert d["parity_fp16"]["logits_max_rel"] <= 1e-3 and d["parity_fp16"]["adapted_logits_max_rel"] <= 1e-3
-    f16 = d["fp16"]["roofline"]
-    assert f16["bound"] == "mfma" and abs(f16["frac"] - f16["achieved"] / f16["peak"]) < 1e-3 and f16["achieved"] > 100
+
+
+def test_bench_refuses_a_swapped_library_unless_asked():
+    """TTL_HIP_LIB_* overrides (the A/B tools' way of loading another build) are an error for a plain bench run."""
+    env = dict(os.environ, TTL_HIP_LIB_BF16=os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd", "ttl_amd", "libttl_hip.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "--variant-lib" in (r.stderr + r.stdout)
+    d = _run(["--steps", "6", "--repeats", "2", "--variant-lib"], env=env)
+    assert d["protocol"]["variant_lib_env"] == ["TTL_HIP_LIB_BF16"] and d["lib_path"].endswith("libttl_hip.so")
 
 
 def test_bench_runs_the_north_star_adapter_set():
     """--lora-targets qkvo: adapters on q, k, v and out_proj (BASELINE.json north_star; the reference ships q, v)."""
     d = _run(["--steps", "6", "--repeats", "2", "--lora-targets", "qkvo"])
     assert d["config"]["lora_targets"] == ["q_proj", "k_proj", "v_proj", "out_proj"] and "q+k+v+out" in d["config"]["workload"]
-    assert d["value"] > 50 and d["repeats"] == 2
+    assert d["value"] > 50 and d["repeats"] >= 2 and d["dtype"] == "bf16" and list(d["legs"]) == ["bf16"]
 
 
 def test_rccl_process_group_of_one_rank_carries_the_accumulator():
@@ -81,9 +105,9 @@ print("RCCL_OK")
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-def _run(extra):
+def _run(extra, env=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--warmup", "2", "--no-cpu-baseline", "--no-parity",
-                        "--no-fp16-leg", "--streams", "2"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--precision", "bf16", "--streams", "2"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -100,3 +124,7 @@ def test_two_ranks_started_by_bench_itself_equal_one_rank():
     assert two["accuracy_accumulator"]["images"] == 12 == one["accuracy_accumulator"]["images"]
     for k in ("top1_hits", "top5_hits"):
         assert two["accuracy_accumulator"][k] == one["accuracy_accumulator"][k], k
+    # the N > 1 line shows every rank: its own rate before the closing barrier, the balance verdict, the graph regime per rank
+    assert len(two["per_rank_value"]) == 2 and all(v > 10 for v in two["per_rank_value"])
+    assert set(two["rank_balance"]) >= {"slowest_over_median", "ok"} and two["config"]["hip_graph_per_rank"] == [True, True]
+    assert two["config"]["backend"] == "gloo" and "per_rank_value" not in one

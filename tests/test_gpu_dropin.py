@@ -432,3 +432,48 @@ def test_weights_from_a_local_hf_checkpoint_directory(tmp_path, monkeypatch):
     with torch.no_grad():
         z1 = model(torch.from_numpy(x).cuda()).cpu().numpy()
     assert np.abs(z1 - z).max() > 1e-4
+
+
+def test_eval_loop_killed_and_resumed_equals_the_uninterrupted_run(tmp_path):
+    """driver.ShardProgress on the GPU evaluation loop (the reference's loop, ttl.py:321-356, keeps its meters in memory only): the
+    data source dies after 11 of 20 images with three episodes in flight; a second call with the same progress file continues
+    after the last recorded image (the accumulator fetch drains the streams, so nothing in flight is counted twice or lost) and
+    ends with exactly the accumulator of an uninterrupted run; a file written under another tag is not picked up."""
+    from ttl_amd.eval import test_time_adapt_eval, SyntheticViews, resume_tag
+    from ttl_amd.driver import ShardProgress
+    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+    args = ref_args()
+    data = SyntheticViews(cfg, 20, 8, 10, seed=5)
+    with torch.no_grad():
+        model.LoRA_reset()
+    full = test_time_adapt_eval(data, model, None, opt, opt_state, None, args, n_streams=3)
+
+    class Dying:
+        def __init__(self, n):
+            self.n, self.served = n, []
+
+        def __iter__(self):
+            for i, item in enumerate(data):
+                if len(self.served) >= self.n:
+                    raise KeyboardInterrupt
+                self.served.append(i)
+                yield item
+    path = str(tmp_path / "run")
+    dying = Dying(11)
+    with pytest.raises(KeyboardInterrupt):
+        test_time_adapt_eval(dying, model, None, opt, opt_state, None, args, n_streams=3, progress=ShardProgress(path, 0, 1, tag="t", every=4))
+    start, acc = ShardProgress(path, 0, 1, tag="t", every=4).resume()
+    assert start == 8 and acc[2] == 8                       # the last multiple of `every` that was accounted for
+    second = Dying(10 ** 9)
+    res = test_time_adapt_eval(second, model, None, opt, opt_state, None, args, n_streams=3, progress=ShardProgress(path, 0, 1, tag="t", every=4))
+    assert res == full
+    assert ShardProgress(path, 0, 1, tag="t").resume() == (20, ShardProgress(path, 0, 1, tag="t").resume()[1]) and ShardProgress(path, 0, 1, tag="t").resume()[1][2] == 20
+    assert ShardProgress(path, 0, 1, tag="other").resume() == (0, [0, 0, 0])
+    # the tag of the CLI names every argument that changes a result
+    import argparse
+    a = argparse.Namespace(arch="ViT-B/16", images=8, views=64, classes=200, rank=16, lr=5e-3, tta_steps=1, selection_p=0.1, filter_ent=0,
+                           deyo_selection=True, deyo_margin_e0=0.4, reweight_ent=1, streams=3, precision="bf16", gpu_views=0, lora_encoder="image", seed=0)
+    base = resume_tag(a)
+    for k, v in dict(precision="fp16", tta_steps=2, lr=1e-3, selection_p=0.2, filter_ent=1, deyo_margin_e0=0.5, reweight_ent=0, seed=1, views=32).items():
+        b = argparse.Namespace(**{**vars(a), k: v})
+        assert resume_tag(b) != base, k

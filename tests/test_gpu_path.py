@@ -7,6 +7,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import ttl_oracle as O
 from helpers import load_case, episode_kwargs, max_rel, check_lora_step, adamw_first_step
+from bounds import check as bound
 
 pytestmark = pytest.mark.gpu
 
@@ -44,9 +45,11 @@ def test_forward_logits(name):
     zb = net.logits(net.forward(x), tf)
     # same rounding points, different summation order: tight
     # (the T=197 toy is hypersensitive: its P is rounded against a running max in the chunked softmax)
-    assert max_rel(z, zb) < (2.5e-2 if name == "tiny197_deyo" else 1.2e-2), ("vs bf16-emulating oracle", max_rel(z, zb))
+    # (ceilings: the documented price of bf16 operands on the toy geometries; the bound asserted is the MEASURED value x 1.3,
+    # tests/bounds.py)
+    bound(f"forward_logits/{name}/vs_bf16_oracle", max_rel(z, zb), 2.5e-2 if name == "tiny197_deyo" else 1.2e-2)
     # vs the reference's fp32 result: bf16 operands cost ~1e-2 of the logit range on these models
-    assert max_rel(z, g["logits0"]) < 3e-2, ("vs reference fp32", max_rel(z, g["logits0"]))
+    bound(f"forward_logits/{name}/vs_reference", max_rel(z, g["logits0"]), 3e-2)
     eng.close()
 
 
@@ -86,8 +89,8 @@ def test_episode(name):
             if np.abs(gref).max() == 0:
                 assert not grads[k].any(), k                     # dA == 0 exactly while B == 0 (Q11)
             else:
-                assert max_rel(grads[k], trace[-1]["grads"][k]) < 2.5e-2, k
-                assert max_rel(grads[k], gref) < 4e-2, k
+                bound(f"episode/{name}/grad_vs_bf16_oracle", max_rel(grads[k], trace[-1]["grads"][k]), 2.5e-2)
+                bound(f"episode/{name}/grad_vs_reference", max_rel(grads[k], gref), 4e-2)
             # (2) the AdamW kernel is exact given ITS gradient
             exp = adamw_first_step(lora0[k], grads[k], kw["lr"])
             assert np.abs(lora1[k] - exp).max() < 2e-8 + 1e-6 * np.abs(exp).max(), k
@@ -100,8 +103,8 @@ def test_episode(name):
             d = np.abs(lora1[k] - g["lora1/" + k])
             assert d.max() <= n_up * 2 * kw["lr"] * 1.01 + 1e-3 * np.abs(g["lora1/" + k]).max(), k
             assert (d > 1e-3).mean() < 0.35, (k, float((d > 1e-3).mean()))
-    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 1.5e-2
-    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 3e-2
+    bound(f"episode/{name}/logits1_vs_bf16_oracle", max_rel(l1.cpu().numpy(), ob["logits1"]), 1.5e-2)
+    bound(f"episode/{name}/logits1_vs_reference", max_rel(l1.cpu().numpy(), g["logits1"]), 3e-2)
     assert np.array_equal(np.argmax(l1.cpu().numpy(), 1), g["top5"][:, 0])
     eng.close()
 
@@ -196,9 +199,9 @@ def test_vit_b16_against_reference_goldens(name):
                          want_logits0=True)
     torch.cuda.synchronize()
     z0 = l0.cpu().numpy()
-    assert max_rel(z0, g["logits0"]) < 8e-3 * ts
+    bound(f"goldens/{name}/bf16/logits0", max_rel(z0, g["logits0"]), 8e-3 * ts)
     H = O.softmax_entropy(z0)
-    np.testing.assert_allclose(H, g["H"], rtol=0, atol=2.5e-2)
+    bound(f"goldens/{name}/bf16/entropy_abs", np.abs(H - g["H"]).max(), 2.5e-2)
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
     assert np.array_equal(np.sort(idx), np.sort(g["idx"])), "confidence-selection set differs from the reference"
     hip_idx, _ = eng.last_selection(x.shape[0])     # the list the HIP episode itself used (set; order: see test_episode)
@@ -211,11 +214,11 @@ def test_vit_b16_against_reference_goldens(name):
             assert not grads[k].any(), k
             assert np.abs(lora1[k] - g["lora1/" + k]).max() < 1e-7, k     # A' = A(1 - lr*wd) exactly (Q11)
         else:
-            assert max_rel(grads[k], gref) < 1.5e-2 * ts, (k, max_rel(grads[k], gref))
+            bound(f"goldens/{name}/bf16/grad", max_rel(grads[k], gref), 1.5e-2 * ts)
             dg = np.abs(grads[k] - gref).max() * 1.001
             check_lora_step(lora1[k], g["lora1/" + k], gref, kw["lr"], 1e-3, k, dg=dg)
-            assert (np.abs(lora1[k] - g["lora1/" + k]) > 1e-4).mean() < 0.02, k  # >98% of B' within 1e-4
-    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 8e-3 * ts
+            bound(f"goldens/{name}/bf16/frac_B_beyond_1e-4", (np.abs(lora1[k] - g["lora1/" + k]) > 1e-4).mean(), 0.02)  # >98% of B' within 1e-4
+    bound(f"goldens/{name}/bf16/logits1", max_rel(l1.cpu().numpy(), g["logits1"]), 8e-3 * ts)
     assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
     eng.close()
 
@@ -235,10 +238,10 @@ def test_r32_four_updates_against_the_reference(precision):
                          mode=1 if kw["mode"] == "topk" else 0, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"], want_logits0=True)
     torch.cuda.synchronize()
     tol = 8e-3 if precision == "bf16" else 1e-3
-    assert max_rel(l0.cpu().numpy(), g["logits0"]) < tol
+    bound(f"r32_steps2/{precision}/logits0", max_rel(l0.cpu().numpy(), g["logits0"]), tol)
     hip_idx, _ = eng.last_selection(x.shape[0])
     assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1)))
-    assert max_rel(l1.cpu().numpy(), g["logits1"]) < 3 * tol
+    bound(f"r32_steps2/{precision}/logits1", max_rel(l1.cpu().numpy(), g["logits1"]), 3 * tol)
     assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
     lora1 = split(flat, lora0, names)
     lr = kw["lr"]
@@ -246,7 +249,7 @@ def test_r32_four_updates_against_the_reference(precision):
         err = np.abs(lora1[k].astype(np.float64) - g["lora1/" + k])
         assert err.max() <= 2 * lr * 4 + 1e-6, (k, float(err.max()))
         if np.abs(g["grad/" + k]).max() > 0:
-            assert (err > 0.1 * lr).mean() < (0.05 if precision == "bf16" else 0.02), (k, float((err > 0.1 * lr).mean()))
+            bound(f"r32_steps2/{precision}/frac_beyond_0.1lr", (err > 0.1 * lr).mean(), 0.05 if precision == "bf16" else 0.02)
     eng.close()
 
 
@@ -268,13 +271,13 @@ def test_other_geometries_forward_and_step_vs_oracle(arch):
     torch.cuda.synchronize()
     trace = []
     ob = O.episode(cfg, W, lora0, x, tf, prec="bf16", trace=trace)
-    assert max_rel(l0.cpu().numpy(), ob["logits0"]) < 1e-2
-    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 1e-2
+    bound(f"other_geometries/{arch}/logits0_vs_bf16_oracle", max_rel(l0.cpu().numpy(), ob["logits0"]), 1e-2)
+    bound(f"other_geometries/{arch}/logits1_vs_bf16_oracle", max_rel(l1.cpu().numpy(), ob["logits1"]), 1e-2)
     grads = split(eng.grads, lora0, names)
     for k in names:
         gr = trace[-1]["grads"][k]
         if np.abs(gr).max() > 0:
-            assert max_rel(grads[k], gr) < 2.5e-2, k
+            bound(f"other_geometries/{arch}/grad_vs_bf16_oracle", max_rel(grads[k], gr), 2.5e-2)
     eng.close()
 
 
@@ -302,20 +305,20 @@ def test_vit_l14_64_views():
     assert torch.equal(a, b) and torch.equal(p_a, flat)                  # bitwise reproducible + complete reset
     assert len(idx64) == 64 and torch.isfinite(a).all() and torch.isfinite(z64).all()
     full = eng.forward(x[:1])
-    assert max_rel(full.cpu().numpy(), a.cpu().numpy()) < 2e-3          # resumed-at-layer-21 == full forward (bf16 noise level)
+    bound("l14_64/resumed_vs_full", max_rel(full.cpu().numpy(), a.cpu().numpy()), 2e-3)          # resumed-at-layer-21 == full forward (bf16 noise level)
     # 8 views: the same context, vs the oracle
     l1, l0 = eng.episode(x[:8], snap, m, v, want_logits0=True)
     torch.cuda.synchronize()
     assert max_rel(l0.cpu().numpy(), z64[:8].cpu().numpy()) < 1e-5       # a view's logits do not depend on its batch
     trace = []
     ob = O.episode(cfg, W, lora0, xh[:8], tf, prec="bf16", trace=trace)
-    assert max_rel(l0.cpu().numpy(), ob["logits0"]) < 1e-2
-    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 1e-2
+    bound("l14_64/8views_logits0_vs_bf16_oracle", max_rel(l0.cpu().numpy(), ob["logits0"]), 1e-2)
+    bound("l14_64/8views_logits1_vs_bf16_oracle", max_rel(l1.cpu().numpy(), ob["logits1"]), 1e-2)
     grads = split(eng.grads, lora0, names)
     for k in names:
         gr = trace[-1]["grads"][k]
         if np.abs(gr).max() > 0:
-            assert max_rel(grads[k], gr) < 2.5e-2, k
+            bound("l14_64/8views_grad_vs_bf16_oracle", max_rel(grads[k], gr), 2.5e-2)
     eng.close()
 
 
@@ -335,9 +338,9 @@ def test_r32_16_views_4_updates_vs_oracle():
     l1, l0 = eng.episode(torch.from_numpy(xh).cuda(), snap, m, v, n_updates=4, mode=1, rho=0.25, want_logits0=True)
     torch.cuda.synchronize()
     ob = O.episode(cfg, W, lora0, xh, tf, prec="bf16", mode="topk", rho=0.25, n_updates=4)
-    assert max_rel(l0.cpu().numpy(), ob["logits0"]) < 1e-2
+    bound("r32_16views/logits0_vs_bf16_oracle", max_rel(l0.cpu().numpy(), ob["logits0"]), 1e-2)
     # 4 sign-like AdamW steps of lr amplify operand-rounding differences in the adapters; the adapted logits still agree
-    assert max_rel(l1.cpu().numpy(), ob["logits1"]) < 3e-2
+    bound("r32_16views/logits1_vs_bf16_oracle", max_rel(l1.cpu().numpy(), ob["logits1"]), 3e-2)
     assert int(l1.argmax()) == int(np.argmax(ob["logits1"]))
     hip_idx, _ = eng.last_selection(16)
     assert len(hip_idx) == int(16 * 0.25)
@@ -367,7 +370,7 @@ def test_r32_128_views_multi_step_invariants():
     # resumed-at-layer-9 inference == full forward: same math, but the 1-view call sums fc2's K in
     # split-K slices; an fp32 round-off difference can flip a later bf16 rounding, so the two agree
     # at the bf16-pipeline noise level (~5e-4 of the logit range), not bitwise
-    assert max_rel(full.cpu().numpy(), a.cpu().numpy()) < 2e-3
+    bound("r32_128views/resumed_vs_full", max_rel(full.cpu().numpy(), a.cpu().numpy()), 2e-3)
     assert torch.isfinite(a).all()
     eng.close()
 
@@ -392,7 +395,7 @@ def test_fp16_operands_meet_the_1e3_tolerance(name):
     # 1e-3 on the real geometry; the D=128 / K=10 / T=197 toy has nearly uniform logits (H in [2.08,2.19] of
     # ln 10 = 2.30), i.e. a tiny logit range to be relative to, and sits at 2.5-6.5e-3 depending on summation order
     TOL = 1e-2 if name == "tiny197_deyo" else 1e-3
-    assert max_rel(z0, g["logits0"]) < TOL, max_rel(z0, g["logits0"])
+    bound(f"goldens/{name}/fp16/logits0", max_rel(z0, g["logits0"]), TOL)
     H = O.softmax_entropy(z0)
     idx = O.select_views(H, kw["mode"], x.shape[0], kw["rho"])
     assert np.array_equal(np.sort(idx), np.sort(g["idx"]))
@@ -412,12 +415,12 @@ def test_fp16_operands_meet_the_1e3_tolerance(name):
             # loss gradient amplifies the 5e-4 logit deviation.  The K = 1000 / every-view-selected case used to sit at 8e-3
             # (dS = P o (dP - delta) in fp16 subnormals under the 2^10 loss scale); dS is now pre-scaled by 2^8 (common.hpp).
             GT = 4 * TOL
-            assert max_rel(grads[k], gref) < GT, (k, max_rel(grads[k], gref))
+            bound(f"goldens/{name}/fp16/grad", max_rel(grads[k], gref), GT)
             dg = np.abs(grads[k] - gref).max() * 1.001
             check_lora_step(lora1[k], g["lora1/" + k], gref, kw["lr"], TOL, k, dg=dg)
             # every element further than TOL from the reference must be one whose gradient is smaller than
             # the gradient error (sign-like first step, Q11) -- check_lora_step above enforces exactly that
-    assert max_rel(l1.cpu().numpy(), g["logits1"]) < TOL, max_rel(l1.cpu().numpy(), g["logits1"])
+    bound(f"goldens/{name}/fp16/logits1", max_rel(l1.cpu().numpy(), g["logits1"]), TOL)
     assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
     eng.close()
 
@@ -606,18 +609,21 @@ def test_k_and_out_proj_adapters_vs_oracle(arch, rank, targets):
         snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
         l1, l0 = eng.episode(torch.from_numpy(x).cuda(), snap, m, v, want_logits0=True)
         torch.cuda.synchronize()
-        assert max_rel(l0.cpu().numpy(), o32["logits0"]) < ltol, precision
+        tag = f"qkvo_oracle/{arch}/r{rank}/{'+'.join(t[0] for t in targets)}/{precision}"
+        bound(tag + "/logits0", max_rel(l0.cpu().numpy(), o32["logits0"]), ltol)
         grads = split(eng.grads, lora0, names)
         for k in names:
             gr = tr32[-1]["grads"][k]
             assert np.abs(gr).max() > 0, k
             cos = float((grads[k] * gr).sum() / (np.linalg.norm(grads[k]) * np.linalg.norm(gr)))
-            assert max_rel(grads[k], gr) < gtol and cos > (0.999 if precision == "fp16" else 0.99), (precision, k, max_rel(grads[k], gr), cos)
+            # (gtol is only the ceiling: the asserted bound is the measured figure x 1.3 per configuration, tests/bounds.py)
+            bound(tag + "/grad", max_rel(grads[k], gr), gtol)
+            bound(tag + "/one_minus_cos", 1.0 - cos, 1e-3 if precision == "fp16" else 1e-2)
         lora1 = split(flat, lora0, names)
         for k in names:
             exp = adamw_first_step(lora0[k], grads[k], 5e-3)
             assert np.abs(lora1[k] - exp).max() < 2e-8 + 1e-6 * np.abs(exp).max(), k
-        assert max_rel(l1.cpu().numpy(), o32["logits1"]) < 3 * ltol, precision
+        bound(tag + "/logits1", max_rel(l1.cpu().numpy(), o32["logits1"]), 3 * ltol)
         eng.close()
 
 

@@ -228,3 +228,55 @@ def test_hf_checkpoint_directory_loader(tmp_path):
     assert tuple(ids.shape) == (2, 77) and ids.dtype == torch.int64
     eot = ids.argmax(-1)
     assert (ids[torch.arange(2), eot] == len(vocab) - 1).all() and eot[1] > eot[0] > 5
+
+
+def test_numa_pinning_skips_kfd_nodes_the_container_may_not_read(tmp_path):
+    """The 1-GPU bench boxes: /sys/class/kfd lists all 8 GPUs of the host, but the properties of 7 of them answer EPERM (device
+    cgroup) and ROCR_VISIBLE_DEVICES=0 / HIP_VISIBLE_DEVICES=0 name the ONE GPU the runtime enumerates.  Round 3 gave up at the
+    first EPERM ("not readable from sysfs", BENCH_r03); the readable GPU node is the answer.  Not testable as root (root reads
+    through mode 000), so the unreadable nodes are directories WITHOUT a properties file opened through a wrapper that raises."""
+    import builtins
+    import os
+    from ttl_amd import driver
+    sysfs = tmp_path
+    props = {0: "simd_count 0\ndrm_render_minor 0\n", 1: "simd_count 0\ndrm_render_minor 0\n", 4: "simd_count 1024\ndrm_render_minor 144\n"}
+    for n in range(10):
+        d = sysfs / "class/kfd/kfd/topology/nodes" / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(props.get(n, "simd_count 1024\ndrm_render_minor 128\n"))
+    d = sysfs / "class/drm/renderD144/device"
+    d.mkdir(parents=True)
+    (d / "numa_node").write_text("1\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    for node in (0, 1):
+        nd = sysfs / f"devices/system/node/node{node}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(",".join(str(c) for c in allowed) + "\n")
+    real_open = builtins.open
+
+    def guarded(path, *a, **k):
+        sp = str(path)
+        if sp.endswith("/properties") and int(sp.split("/")[-2]) not in props:
+            raise PermissionError(1, "Operation not permitted", sp)
+        return real_open(path, *a, **k)
+    builtins.open = guarded
+    try:
+        node, cpus, src = driver.gpu_numa_cpus(0, str(sysfs), env={"ROCR_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"}, with_source=True)
+    finally:
+        builtins.open = real_open
+    assert (node, src) == (1, "kfd") and cpus == set(allowed)
+
+
+def test_resume_tag_names_every_result_affecting_argument():
+    """round-3 advisor (eval.py:245): a progress file written under another --precision / --tta_steps / --lr / selection / margin /
+    reweighting / seed must not be resumed from."""
+    import argparse
+    from ttl_amd.eval import resume_tag, RESUME_TAG_FIELDS
+    a = argparse.Namespace(arch="ViT-B/16", images=8, views=64, classes=200, rank=16, lr=5e-3, tta_steps=1, selection_p=0.1, filter_ent=0,
+                           deyo_selection=True, deyo_margin_e0=0.4, reweight_ent=1, streams=3, precision="bf16", gpu_views=0, lora_encoder="image", seed=0)
+    assert set(RESUME_TAG_FIELDS) == set(vars(a))
+    base = resume_tag(a)
+    changed = dict(arch="ViT-L/14", images=9, views=32, classes=10, rank=32, lr=1e-3, tta_steps=2, selection_p=0.2, filter_ent=1, deyo_selection=False,
+                   deyo_margin_e0=0.5, reweight_ent=0, streams=2, precision="fp16", gpu_views=1, lora_encoder="text", seed=1)
+    for k, v in changed.items():
+        assert resume_tag(argparse.Namespace(**{**vars(a), k: v})) != base, k

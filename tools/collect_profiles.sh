@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-python3 bench.py --streams 1 --no-cpu-baseline --no-parity --no-fp16-leg > $O/bench_streams1.json 2>> $O/bench.err
-Q="--no-cpu-baseline --no-parity --no-fp16-leg"
+python3 bench.py --streams 1 --no-cpu-baseline --no-parity --precision bf16 > $O/bench_streams1.json 2>> $O/bench.err
+Q="--no-cpu-baseline --no-parity --precision bf16"
 rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 $Q > $O/prof1.log 2>&1
 python3 bench.py --lora-targets qkvo $Q > $O/bench_qkvo.json 2>> $O/bench.err
 python3 bench.py --graph 0 $Q > $O/bench_graph0.json 2>> $O/bench.err

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""measured.json (written by a `TTL_RECORD_BOUNDS=... pytest -m gpu` run on MI355X) -> tests/golden/bounds.json.
+
+bound = measured x 1.3, rounded up to 3 significant digits; quantities that measure (almost) zero get a floor of 1e-6 so that a
+last-bit change of a summation order cannot fail them.  tests/bounds.py applies them on top of each assertion's documented ceiling."""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MARGIN, FLOOR = 1.3, 1e-6
+
+
+def up3(v):
+    if v <= 0:
+        return FLOOR
+    e = math.floor(math.log10(v)) - 2
+    return round(math.ceil(v / 10 ** e) * 10 ** e, 12)
+
+
+def main():
+    src = sys.argv[1]
+    meas = json.load(open(src))
+    out = {"note": "tools/derive_test_bounds.py: bound = measured-on-MI355X x %.1f (3 significant digits, floor %g); "
+                   "regenerate after any kernel change that moves a summation order" % (MARGIN, FLOOR),
+           "margin": MARGIN, "measured": {k: meas[k] for k in sorted(meas)},
+           "bounds": {k: max(up3(meas[k] * MARGIN), FLOOR) for k in sorted(meas)}}
+    dst = os.path.join(ROOT, "tests", "golden", "bounds.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"{len(meas)} bounds -> {dst}")
+
+
+if __name__ == "__main__":
+    main()

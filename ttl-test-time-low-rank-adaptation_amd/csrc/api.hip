@@ -462,6 +462,11 @@ int ttl_load_weight_typed(ttl_ctx* c, const char* name, const void* data, size_t
 int ttl_load_weight(ttl_ctx* c, const char* name, const float* data, size_t count) {
     if (!c || !name || !data) return fail(TTL_EINVAL, "null argument");
     if (c->parent) return fail(TTL_ESTATE, "%s: this context shares its parent's weights (ttl_ctx_create_shared); load them into the parent", name);
+    // sharing freezes the owner's weights: the sharers read its frozen images in place and hold private COPIES of the projection
+    // images of the adapter layers, taken at creation — a later load would leave one model with tensors of two generations
+    if (c->refs.load() > 1)
+        return fail(TTL_ESTATE, "%s: %d context(s) share this context's weight images (ttl_ctx_create_shared); destroy them before loading weights",
+                    name, c->refs.load() - 1);
     const size_t D = c->D, F = c->F, E = c->E, T = c->T;
     float* tmp = nullptr;
     int rc = 0;

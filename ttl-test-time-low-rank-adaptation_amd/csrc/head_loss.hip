@@ -21,6 +21,7 @@ namespace {
 #define TTL_HEAD_SLICES 4
 #endif
 constexpr int NS = TTL_HEAD_SLICES;
+static_assert(NS >= 4 && NS % 4 == 0 && NS <= 16, "TTL_HEAD_SLICES must be 4, 8, 12 or 16 (matvec64 reduces the slices four at a time)");
 constexpr int HB = 64 * NS;  // threads per head block
 
 __device__ __forceinline__ float block_sum(float v, float* red) {

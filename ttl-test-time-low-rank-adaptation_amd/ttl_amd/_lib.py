@@ -11,8 +11,11 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libttl_hip.so")            # bf16 operands (default; BASELINE north_star)
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libttl_hip_fp16.so")}   # same ABI, operand dtype differs
-if os.environ.get("TTL_HIP_LIB_BF16"):     # A/B timing of experimental builds (tools/): another bf16 build of the same ABI
-    LIB_PATHS["bf16"] = os.environ["TTL_HIP_LIB_BF16"]
+# A/B timing of experimental builds (tools/): another build of the same ABI for one operand dtype.  bench.py refuses to run under
+# such an override unless --variant-lib is passed, and records path + sha256 of what it loaded either way.
+for _prec, _var in (("bf16", "TTL_HIP_LIB_BF16"), ("fp16", "TTL_HIP_LIB_FP16")):
+    if os.environ.get(_var):
+        LIB_PATHS[_prec] = os.environ[_var]
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ttl_hip.h"))
 
 TTL_SEL_LE_THRESH = 0

@@ -27,41 +27,162 @@ def _parse_cpulist(text):
     return cpus
 
 
-def gpu_numa_cpus(local_rank, sysfs="/sys", env=None):
-    """(numa node, set of CPUs) of the NUMA node the ``local_rank``-th VISIBLE GPU hangs off, read from sysfs without touching
-    the GPU: KFD topology nodes with simd_count > 0 are the GPUs in the runtime's enumeration order, HIP_VISIBLE_DEVICES /
-    ROCR_VISIBLE_DEVICES select and reorder them, the node's drm_render_minor leads to .../device/numa_node.
-    (None, None) when any of it cannot be read (containers without /sys/class/kfd, numa_node == -1)."""
-    env = os.environ if env is None else env
-    try:
-        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
-        gpus = []
-        for n in sorted(os.listdir(base), key=int):
+def _visible_gpus(n_physical, env):
+    """Indices (into the runtime's physical enumeration) of the GPUs this process sees, in the order HIP numbers them, or None when the
+    environment cannot be resolved safely.  ROCR_VISIBLE_DEVICES filters / reorders the physical list first; HIP_VISIBLE_DEVICES (or
+    CUDA_VISIBLE_DEVICES, which HIP honours too) then indexes INTO that subset.  Entries that are not plain indices (GPU-xxxx UUIDs),
+    out-of-range indices, or HIP_ and CUDA_ lists that disagree -> None: no pin is better than a pin to the wrong socket."""
+    def parse(name):
+        v = env.get(name)
+        if v is None or v.strip() == "":
+            return None
+        out = []
+        for t in v.split(","):
+            t = t.strip()
+            if not t.isdigit():
+                return False
+            out.append(int(t))
+        return out
+    rocr, hipv, cudav = parse("ROCR_VISIBLE_DEVICES"), parse("HIP_VISIBLE_DEVICES"), parse("CUDA_VISIBLE_DEVICES")
+    if rocr is False or hipv is False or cudav is False:
+        return None
+    if hipv is not None and cudav is not None and hipv != cudav:
+        return None
+    ids = list(range(n_physical))
+    for lst in (rocr, hipv if hipv is not None else cudav):
+        if lst is None:
+            continue
+        if any(i >= len(ids) for i in lst):
+            return None
+        ids = [ids[i] for i in lst]
+    return ids
+
+
+def _gpus_from_kfd(sysfs):
+    """[(numa node or None, pci address or None)] of the GPUs in the runtime's enumeration order: KFD topology nodes with
+    simd_count > 0; a node's drm_render_minor leads to /sys/class/drm/renderD<minor>/device/numa_node.  A node whose properties
+    file may not be read (EPERM: a container's device cgroup admits only the leased GPUs — seen on the 1-GPU bench boxes, where 7 of
+    the 8 GPU nodes answer "Operation not permitted") is a GPU the runtime of this process does not enumerate either: skipped."""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    gpus = []
+    for n in sorted(os.listdir(base), key=int):
+        try:
             props = dict(l.split()[:2] for l in open(os.path.join(base, n, "properties")) if len(l.split()) >= 2)
-            if int(props.get("simd_count", 0)) > 0:
-                gpus.append(int(props["drm_render_minor"]))
-        vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
-        if vis:
-            gpus = [gpus[int(v)] for v in vis.split(",") if v.strip().isdigit() and int(v) < len(gpus)]
-        minor = gpus[local_rank]
-        node = int(open(os.path.join(sysfs, f"class/drm/renderD{minor}/device/numa_node")).read())
-        if node < 0:
-            return None, None
-        return node, _parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read())
-    except (OSError, ValueError, IndexError, KeyError):
-        return None, None
+        except PermissionError:
+            continue
+        if int(props.get("simd_count", 0)) > 0:
+            dev = os.path.join(sysfs, f"class/drm/renderD{int(props['drm_render_minor'])}/device")
+            gpus.append((int(open(os.path.join(dev, "numa_node")).read()), os.path.basename(os.path.realpath(dev))))
+    return gpus
 
 
-def pin_to_gpu_numa_node(local_rank, n_local_ranks=1, sysfs="/sys", env=None, apply=True):
+def _gpus_from_drm(sysfs, devfs=None):
+    """The same list without KFD (containers that hide /sys/class/kfd): AMD (vendor 0x1002) display / accelerator functions behind
+    /sys/class/drm/renderD*, ordered by PCI address — the order the ROCm runtime enumerates a node's GPUs in on every box seen.
+    sysfs shows every GPU of the host even when the container may open only some: with ``devfs`` (default /dev/dri for the real
+    /sys) only the render nodes this process can open count."""
+    base = os.path.join(sysfs, "class/drm")
+    if devfs is None and sysfs == "/sys":
+        devfs = "/dev/dri"
+    found = {}
+    for c in os.listdir(base):
+        if not c.startswith("renderD"):
+            continue
+        dev = os.path.join(base, c, "device")
+        try:
+            if int(open(os.path.join(dev, "vendor")).read(), 16) != 0x1002:
+                continue
+            cls = int(open(os.path.join(dev, "class")).read(), 16) >> 16 if os.path.exists(os.path.join(dev, "class")) else 0x03
+            if cls not in (0x03, 0x12):                   # display controller / processing accelerator
+                continue
+            if devfs and os.path.isdir(devfs) and not os.access(os.path.join(devfs, c), os.R_OK | os.W_OK):
+                continue
+            found[os.path.basename(os.path.realpath(dev))] = int(open(os.path.join(dev, "numa_node")).read())
+        except (OSError, ValueError):
+            continue
+    def key(addr):
+        try:
+            dom, bus, rest = addr.split(":")
+            d, f = rest.split(".")
+            return (int(dom, 16), int(bus, 16), int(d, 16), int(f, 16))
+        except ValueError:
+            return (1 << 30, 0, 0, 0)
+    return [(found[a], a) for a in sorted(found, key=key)]
+
+
+def _gpus_from_rocm_smi(timeout=20):
+    """Last resort: ask `rocm-smi --showtoponuma --json` from a CHILD process (this process must not touch the GPU before it has
+    pinned itself).  -> [(numa node, None)] in card order."""
+    import json
+    import subprocess
+    r = subprocess.run(["rocm-smi", "--showtoponuma", "--json"], capture_output=True, text=True, timeout=timeout)
+    d = json.loads(r.stdout[r.stdout.index("{"):])
+    cards = sorted((k for k in d if k.startswith("card")), key=lambda k: int(k[4:]))
+    out = []
+    for k in cards:
+        node = next((v for kk, v in d[k].items() if "numa node" in kk.lower()), None)
+        out.append((int(node), None))
+    return out
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys", env=None, with_source=False, allow_smi=None):
+    """(numa node, set of CPUs) of the NUMA node the ``local_rank``-th VISIBLE GPU hangs off, found without touching the GPU.
+    Sources, in order, each tried only when the one before cannot answer: (1) KFD topology -> drm_render_minor -> numa_node;
+    (2) /sys/class/drm/card*/device/{vendor,numa_node} ordered by PCI address; (3) `rocm-smi --showtoponuma --json` in a child
+    process (only with the real /sys, or ``allow_smi``).  (None, None) when none of them yields a node >= 0 whose cpulist can be read,
+    or when the *_VISIBLE_DEVICES environment cannot be resolved (see _visible_gpus).  with_source: a third element naming what
+    answered or why nothing did."""
+    env = os.environ if env is None else env
+    if allow_smi is None:
+        allow_smi = (sysfs == "/sys")
+    why = []
+    sources = [("kfd", lambda: _gpus_from_kfd(sysfs)), ("drm-pci-order", lambda: _gpus_from_drm(sysfs))]
+    if allow_smi:
+        sources.append(("rocm-smi", _gpus_from_rocm_smi))
+    result = (None, None, None)
+    for name, fn in sources:
+        try:
+            gpus = fn()
+        except Exception as e:      # unreadable / absent: next source
+            why.append(f"{name}: {type(e).__name__}")
+            continue
+        if not gpus:
+            why.append(f"{name}: no GPUs listed")
+            continue
+        vis = _visible_gpus(len(gpus), env)
+        if vis is None:
+            result = (None, None, "unresolvable *_VISIBLE_DEVICES (non-index entries, out-of-range, or HIP/CUDA lists that differ)")
+            break
+        if local_rank >= len(vis):
+            why.append(f"{name}: local rank {local_rank} but {len(vis)} visible GPUs")
+            continue
+        node = gpus[vis[local_rank]][0]
+        if node is None or node < 0:
+            why.append(f"{name}: numa_node {node}")
+            continue
+        try:
+            cpus = _parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read())
+        except (OSError, ValueError):
+            why.append(f"{name}: node{node}/cpulist unreadable")
+            continue
+        result = (node, cpus, name)
+        break
+    if result[2] is None:
+        result = (None, None, "; ".join(why) or "no source")
+    return result if with_source else result[:2]
+
+
+def pin_to_gpu_numa_node(local_rank, n_local_ranks=1, sysfs="/sys", env=None, apply=True, allow_smi=None):
     """Restrict this process (call it BEFORE torch / HIP start their threads and before any GPU call) to the CPUs of its GPU's
     NUMA node, so the episode's ~130 kernel enqueues per image and the allocator's host threads stay next to the device's PCIe
-    root.  Several ranks on one node share its CPUs (the scheduler spreads them).  Returns a small record for the bench line;
-    never raises: an unreadable topology leaves the affinity alone."""
-    node, cpus = gpu_numa_cpus(local_rank, sysfs, env)
+    root.  Several ranks on one node share its CPUs (the scheduler spreads them).  Returns a small record for the bench line
+    (which source answered, or why none did); never raises: an unreadable topology leaves the affinity alone."""
+    node, cpus, src = gpu_numa_cpus(local_rank, sysfs, env, with_source=True, allow_smi=allow_smi)
     rec = {"local_rank": int(local_rank), "numa_node": node, "applied": False}
     if node is None:
-        rec["reason"] = "GPU -> NUMA node not readable from sysfs"
+        rec["reason"] = "GPU -> NUMA node not known: " + str(src)
         return rec
+    rec["source"] = src
     try:
         allowed = os.sched_getaffinity(0)
     except AttributeError:          # pragma: no cover
@@ -161,6 +282,15 @@ class ImageShard:
 
     def max(self, t):
         return self._reduce(t, dist.ReduceOp.MAX)
+
+    def gather(self, t):
+        """[world, t.numel()]: row r = rank r's ``t`` (measurement only — bench.py's per-rank rates; an all-reduce(SUM) of a
+        matrix in which every rank fills its own row, so it rides the same collective the accumulator uses)."""
+        if self.world == 1:
+            return t.reshape(1, -1).clone()
+        buf = torch.zeros((self.world, t.numel()), dtype=t.dtype, device=t.device)
+        buf[self.rank] = t.reshape(-1)
+        return self._reduce(buf, dist.ReduceOp.SUM)
 
     def ranks_seen(self, device="cpu"):
         """Number of ranks that really take part (all-reduce of ones): bench.py prints it next to n_gpus."""

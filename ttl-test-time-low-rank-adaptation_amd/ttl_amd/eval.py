@@ -194,6 +194,17 @@ class SyntheticImages:
             yield self.pool[i % len(self.pool)], i % self.k
 
 
+RESUME_TAG_FIELDS = ("arch", "images", "views", "classes", "rank", "lr", "tta_steps", "selection_p", "filter_ent", "deyo_selection",
+                     "deyo_margin_e0", "reweight_ent", "streams", "precision", "gpu_views", "lora_encoder", "seed")
+
+
+def resume_tag(a):
+    """Identity of a run for driver.ShardProgress: every argument that affects a result (precision, objective, step count,
+    learning rate, selection / margin / reweighting, view generation and its seed) or the work split (streams only changes
+    the order of execution, but it is cheap to be strict).  Two runs with different tags never share a progress file."""
+    return "|".join(f"{k}={getattr(a, k, None)!r}" for k in RESUME_TAG_FIELDS)
+
+
 def main():
     ap = argparse.ArgumentParser(description="TTL evaluation on synthetic views (no datasets on the GPU box)")
     ap.add_argument("--arch", default="ViT-B/16")
@@ -212,6 +223,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic data and of the GPU view generator's crop boxes")
     ap.add_argument("--resume_file", default=None, help="prefix of the per-rank progress files (driver.ShardProgress): a run that "
                     "is started again with the same arguments continues after the last recorded image of every rank")
     a = ap.parse_args()
@@ -231,24 +243,33 @@ def main():
     aug = None
     if a.gpu_views:
         from .views import GpuAugMixAugmenter
-        data = SyntheticImages(a.images, a.classes)
-        aug = GpuAugMixAugmenter(a.views - 1, model.cfg.image_size, precision=a.precision, seed=0)
+        data = SyntheticImages(a.images, a.classes, seed=a.seed)
+        aug = GpuAugMixAugmenter(a.views - 1, model.cfg.image_size, precision=a.precision, seed=a.seed)
     else:
-        data = SyntheticViews(model.cfg, a.images, a.views, a.classes)
+        data = SyntheticViews(model.cfg, a.images, a.views, a.classes, seed=a.seed)
     # untimed first pass: builds the per-stream contexts (weight images, arenas), like loading the model
     test_time_adapt_eval(itertools.islice(iter(data), 2 * world), model, None, opt, None, None, a, n_streams=a.streams, rank=rank,
                          world=world, gpu_augmenter=aug)
     torch.cuda.synchronize()
     t0 = time.time()
-    progress = None
+    progress, resumed_at = None, 0
     if a.resume_file:
-        progress = ShardProgress(a.resume_file, rank, world, tag=f"{a.arch}|{a.images}|{a.views}|{a.classes}|{a.rank}|{a.lora_encoder}|{a.gpu_views}")
+        # the tag names EVERY argument that changes what an item's result is (or which items this rank owns): a progress
+        # file written under any other setting is ignored instead of being mixed into this run's accumulator
+        progress = ShardProgress(a.resume_file, rank, world, tag=resume_tag(a))
+        resumed_at = progress.resume()[0]
+        if resumed_at:
+            print(f"[rank {rank}] resuming from index {resumed_at} of {a.images} ({a.resume_file})", flush=True)
     top1, top5 = test_time_adapt_eval(data, model, None, opt, None, None, a, n_streams=a.streams, rank=rank, world=world, progress=progress,
                                       gpu_augmenter=aug)
     dt = time.time() - t0
+    # throughput over the images this run really processed (a resumed run skips what the file already accounts for)
+    done = torch.tensor([sum(1 for i in range(rank, a.images, world) if i >= resumed_at)], dtype=torch.int64, device=f"cuda:{local}")
+    done = int(ImageShard(rank, world).sum(done).item())
     if rank == 0:
-        print(json.dumps({"top1": top1, "top5": top5, "images": a.images, "world": world, "gpu_views": bool(a.gpu_views),
-                          "images_per_sec_incl_input_generation": round(a.images / dt, 2)}))
+        print(json.dumps({"top1": top1, "top5": top5, "images": a.images, "images_processed_this_run": done,
+                          "resumed_from_index": resumed_at, "world": world, "gpu_views": bool(a.gpu_views),
+                          "images_per_sec_incl_input_generation": round(done / dt, 2) if done else None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,13 +31,64 @@ def _normal(seed, name, shape, std, mean=0.0):
             + np.float32(mean)).astype(np.float32)
 
 
-def vision_weights(cfg: VitConfig, seed: int = 0) -> dict:
+def vision_weights(cfg: VitConfig, seed: int = 0, variant: str = None) -> dict:
     """fp32 state-dict (numpy) for the image tower + projection + logit_scale.
 
     Scales are chosen so that attention is peaked (not uniform), LN affine and biases are
     non-trivial and the residual stream stays O(1) through all layers: a flat synthetic
     model would hide indexing bugs that a peaked one exposes.
+
+    variant="outliers": the same draws, then CLIP-like activation outliers (``add_activation_outliers``).
     """
+    if variant not in (None, "", "outliers"):
+        raise ValueError(f"unknown weights variant {variant!r}")
+    w = _vision_weights_base(cfg, seed)
+    if variant == "outliers":
+        add_activation_outliers(cfg, w, seed)
+    return w
+
+
+OUTLIER_CHANNELS = 4
+
+
+def outlier_layout(cfg: VitConfig, seed: int = 0):
+    """(channels [4], signs [4], patch token index) of the 'outliers' variant: pure function of (cfg.width, cfg.tokens, seed)."""
+    rng = _rng(seed, f"outliers{cfg.width}x{cfg.tokens}")
+    ch = rng.choice(cfg.width, size=OUTLIER_CHANNELS, replace=False)
+    sign = rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=OUTLIER_CHANNELS)
+    tstar = 1 + int(rng.integers(0, cfg.tokens - 1))
+    return ch, sign, tstar
+
+
+def add_activation_outliers(cfg: VitConfig, w: dict, seed: int = 0) -> None:
+    """In place: the activation statistics pretrained CLIP ViTs are known for (the checkpoint the reference loads,
+    ``openai/clip-vit-base-patch16``, clip/custom_clip.py:581, cannot be fetched offline): a handful of residual channels carry
+    30-100x the typical magnitude — on the CLS token and ONE patch token from the embeddings on (class / position embedding,
+    amplified by the pre-LN gain), on EVERY token from an early MLP on (fc2 rows + bias of that channel), while the per-layer
+    LayerNorm gains on those channels are small (the model damps them before every matmul) except one LN2 whose large gain
+    feeds an outlier straight into fc1, and the post-LN gain is small (the pooled feature does not hang on them).
+    Every 16-bit buffer of the HIP path (LN outputs, q/k/v, attention output, the fc1 pre-activation, the backward's
+    counterparts) then holds values two orders of magnitude apart in one row."""
+    ch, sign, tstar = outlier_layout(cfg, seed)
+    pre = "vision_model."
+    L = cfg.layers
+    w[pre + "embeddings.class_embedding"][ch[:3]] += (60.0 * sign[:3]).astype(np.float32)
+    w[pre + "embeddings.position_embedding.weight"][tstar, ch[1:]] += (45.0 * sign[1:]).astype(np.float32)
+    w[pre + "pre_layrnorm.weight"][ch] = 4.0                # normalised outliers (~16 on the CLS row) -> ~64 in the residual stream
+    w[pre + "post_layernorm.weight"][ch] = 0.02
+    for i in range(L):
+        lp = f"{pre}encoder.layers.{i}."
+        for nm in ("layer_norm1", "layer_norm2"):
+            w[lp + nm + ".weight"][ch] = 0.08
+    mid = min(L - 1, max(1, L // 2))
+    w[f"{pre}encoder.layers.{mid}.layer_norm2.weight"][ch[0]] = 2.5     # one LN feeds an outlier into fc1 at full size
+    for i in sorted({min(2, L - 1), min(5, L - 1)}):                      # early MLPs put channel ch[3] on every token
+        lp = f"{pre}encoder.layers.{i}."
+        w[lp + "mlp.fc2.weight"][ch[3], :] *= 12.0
+        w[lp + "mlp.fc2.bias"][ch[3]] += np.float32(25.0 * sign[3])
+
+
+def _vision_weights_base(cfg: VitConfig, seed: int = 0) -> dict:
     D, F, E, P = cfg.width, cfg.mlp, cfg.embed, cfg.patch_size
     T = cfg.tokens
     w = {}
