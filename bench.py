@@ -370,7 +370,7 @@ def main():
         -> (wall s incl. the closing barrier, max over ranks; s spent in submit(); s until this rank alone had finished)"""
         t0 = time.perf_counter()
         for i in shard.indices(world * n_items):
-            pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, n_updates=a.updates)
+            pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, want_output=False, n_updates=a.updates)
         t_enq = time.perf_counter() - t0
         t_local = t_enq + fence(pipe)
         dt = time.perf_counter() - t0
@@ -382,18 +382,20 @@ def main():
 
     # ---- ONE protocol for all legs: the graph regime is decided once, after a warm-up that has exercised every library
     use_graph = (world > 1) if a.graph < 0 else bool(a.graph)
-    why = "--graph" if a.graph >= 0 else ("auto: %d ranks share the host" % world if world > 1 else "auto: off")
+    why = "--graph" if a.graph >= 0 else ("auto: %d ranks share the host" % world if world > 1 else "auto: off (enqueue loop under half of a step)")
     pipes, warm = {}, {}
     for p in legs:
         pipes[p] = make_pipe(p, use_graph)
         fence(pipes[p])
-        warm[p] = block(pipes[p], a.warmup)
-    if a.graph < 0 and not use_graph and a.warmup > 0:
+        block(pipes[p], a.warmup)                    # first use: library initialisation, allocator growth, clocks
+        if a.graph < 0 and not use_graph:
+            warm[p] = block(pipes[p], min(max(a.warmup, 5), 20))     # the probe the graph decision is taken from (untimed)
+    if a.graph < 0 and not use_graph and warm:
         share = max(warm[p][1] / max(warm[p][0], 1e-9) for p in legs)
         if share > 0.5:
             # the enqueue loop is more than half of a step: the host would bound the run as soon as anything else shares its
             # cores -> replay each episode as ONE graph launch (bit-identical results, tests/test_gpu_path.py), for EVERY leg
-            use_graph, why = True, f"auto: enqueue loop took {share:.0%} of the warm-up's wall time"
+            use_graph, why = True, f"auto: the enqueue loop took {share:.0%} of a warmed-up probe block's wall time"
             for p in legs:
                 pipes[p].close()
             for p in legs:
@@ -472,7 +474,7 @@ def main():
 
         def run_all():
             for i in range(nprof):
-                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], persistent_input=True, n_updates=a.updates)
+                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], persistent_input=True, want_output=False, n_updates=a.updates)
             pipe.synchronize()
 
         def run_one():

@@ -210,6 +210,11 @@ typedef struct ttl_episode_args {
     float* exp_avg_sq;
     float* logits0_out;
     float* logits1_out;
+    /* accuracy(output, target, topk=(1, 5)) of utils/tools.py:88-102 on the adapted prediction, counted on the device (ttl.py:354-356
+     * keeps AverageMeters on the host): target = device int64 [1] (the label), hits_out = device int64 [3] += {top-1 hit, top-5 hit
+     * (top-min(5,K)), 1}.  Both NULL: no counting.  Ties rank the lower class index first; a label outside [0, K) never hits. */
+    const int64_t* target;
+    int64_t* hits_out;
 } ttl_episode_args;
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
 

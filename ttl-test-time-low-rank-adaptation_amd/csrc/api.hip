@@ -157,7 +157,7 @@ int check_config(const ttl_config* k) {
     if (!k) return fail(TTL_EINVAL, "null config");
     if (k->width < 128 || k->heads < 1 || k->mlp < 128 || k->layers < 1)      // (before any division by them)
         return fail(TTL_EINVAL, "width / heads / mlp / layers must be positive (got D=%d H=%d F=%d L=%d)", k->width, k->heads, k->mlp, k->layers);
-    if (k->width % 128 || k->width / k->heads != 64 || k->width % k->heads)
+    if (k->width % 128 || k->width > 1024 || k->width / k->heads != 64 || k->width % k->heads)
         return fail(TTL_EINVAL, "width must be a multiple of 128 with head_dim 64 (got D=%d H=%d)", k->width, k->heads);
     if (k->mlp % 128) return fail(TTL_EINVAL, "mlp must be a multiple of 128");
     if (k->rank != 16 && k->rank != 32) return fail(TTL_EINVAL, "rank must be 16 or 32 (got %d)", k->rank);
@@ -171,7 +171,7 @@ int check_config(const ttl_config* k) {
         return fail(TTL_EINVAL, "bad layer range [%d,%d] for %d layers", k->layer_lo, k->layer_hi, k->layers);
     int T = k->tower == TTL_TOWER_TEXT ? k->context_length : (k->image_size / k->patch_size) * (k->image_size / k->patch_size) + 1;
     if (T > 288) return fail(TTL_EINVAL, "token count %d > 288 unsupported", T);
-    if (k->max_views < 1 || k->max_classes < 1 || k->embed < 1 || k->embed > 4096) return fail(TTL_EINVAL, "bad capacities");
+    if (k->max_views < 1 || k->max_classes < 1 || k->embed < 4 || k->embed > 1024 || k->embed % 4) return fail(TTL_EINVAL, "bad capacities (embed must be a multiple of 4 in [4, 1024])");
     if (k->lora_targets < 0 || k->lora_targets > 15) return fail(TTL_EINVAL, "lora_targets must be a mask of TTL_LORA_Q|K|V|O (got %d)", k->lora_targets);
     return 0;
 }
@@ -845,12 +845,15 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     {
         Prof p(c, 5, s);
         if (c->text) HIP_TRY(launch_gather_rows_f32(h, D, c->pool, T, c->hpool, n, D, s));   // end-of-text rows -> [n, D]
-        HeadArgs a = head_args(c, h, feats_out, c->logits);
+        // image tower, forward that is not saved for a backward (the adapted 1-view prediction, plain model(x) calls): the logit
+        // launch writes straight into the caller's buffer; a saved forward keeps c->logits, which the fused loss reads
+        const bool direct = logits_out && !save && !c->text;
+        HeadArgs a = head_args(c, h, feats_out, direct ? logits_out : c->logits);
         HIP_TRY(launch_head_fwd(a, n, s));
         if (c->text && c->K > 0) {   // the head produced [prompts, views]; the loss and the caller want [views, prompts]
             HIP_TRY(launch_transpose_f32(c->logits, n, c->K, c->logits_nk, s));
             if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, c->logits_nk, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
-        } else if (logits_out)
+        } else if (logits_out && !direct)
             HIP_TRY(hipMemcpyAsync(logits_out, c->logits, (size_t)n * c->K * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     c->saved = save != 0;
@@ -935,7 +938,8 @@ int ttl_ctx_tpt_select_loss(ttl_ctx* c, const float* logits, int N, int K, doubl
 }
 
 // ------------------------------------------------------------------------------ backward
-static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) {
+// inf_cleared: the caller's loss launch has already zeroed found_inf on this stream (the fused episode: deyo_select_grad_kernel)
+static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, bool inf_cleared = false) {
     if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");
     if (!c->saved || c->saved_n != n) return fail(TTL_ESTATE, "no saved forward for %d sequences (run the forward with save_for_backward)", n);
     hipStream_t s = (hipStream_t)stream;
@@ -943,7 +947,7 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream) 
     const int causal = c->text;
     const int* pool = c->text ? c->pool : nullptr;
     int rc;
-    HIP_TRY(hipMemsetAsync(c->sc.i + SC_FOUND_INF, 0, sizeof(int), s));   // found_inf describes THIS backward's gradients
+    if (!inf_cleared) HIP_TRY(hipMemsetAsync(c->sc.i + SC_FOUND_INF, 0, sizeof(int), s));   // found_inf describes THIS backward's gradients
     float* dh = c->dh;      // gradient w.r.t. the residual stream at the current depth
     float* dh_alt = c->dh2;
     {
@@ -1178,14 +1182,28 @@ int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, vo
     return 0;
 }
 
+// Launches of an episode outside the towers (round 4): 1 reset (LoRA, Adam moments, scaler step counters),
+// per update 2 head forward (LayerNorm of the pooled rows + projection; norm + logits) + 2 loss (row statistics; selection + loss
+// + dZ, which also clears found_inf) + 3 head backward + 1 optimizer (GradScaler decision + AdamW), then 2 head launches of the
+// adapted prediction writing into the caller's buffer and, with a target, 1 hit-count launch.
+static int episode_tail(ttl_ctx* c, const ttl_episode_args* a, const float* logits1, hipStream_t s) {
+    if (!a->target && !a->hits_out) return 0;
+    if (!a->target || !a->hits_out) return fail(TTL_EINVAL, "target and hits_out go together");
+    Prof p(c, 5, s);
+    HIP_TRY(launch_topk_hits(logits1, c->text ? c->n_prompts : c->K, (const long long*)a->target, (long long*)a->hits_out, s));
+    return 0;
+}
+
 int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (!c || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
     if (c->text) return fail(TTL_ESTATE, "ttl_episode on a text-tower context (use ttl_episode_text)");
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
-    HIP_TRY(launch_scaler_reset_step(c->sc, s));   // optimizer.load_state_dict(empty): step count 0; the loss scale PERSISTS (Q14)
+    {
+        Prof p(c, 5, s);   // LoRA_AB.reset + optimizer.load_state_dict(empty): step count 0; the loss scale PERSISTS (Q14)
+        HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s));
+    }
     for (int u = 0; u < a->n_updates; ++u) {
         if ((rc = forward_impl(c, a->x, a->n_views, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr,
                                stream)))
@@ -1194,21 +1212,21 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
             Prof p(c, 5, s);
             HIP_TRY(launch_entropy_loss(c->logits, a->n_views, c->K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf, c->dlogits,
-                                        c->loss_scratch, s));
+                                        c->loss_scratch, s, nullptr, c->sc.i + SC_FOUND_INF));
         }
-        if ((rc = backward_impl(c, c->dlogits, a->n_views, stream))) return rc;
+        if ((rc = backward_impl(c, c->dlogits, a->n_views, stream, true))) return rc;
         {
             Prof p(c, 5, s);   // scaler.step(optimizer); scaler.update()  (deyo.py:186-188): whole step or nothing
-            HIP_TRY(launch_scaler_pre_step(c->sc, c->n_buf, 0, a->beta1, a->beta2, c->sc_dynamic, c->sc_growth, c->sc_backoff,
-                                           c->sc_interval, s));
-            HIP_TRY(launch_adamw_dev(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                     a->weight_decay, c->sc, s));
+            HIP_TRY(launch_adamw_fused(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s));
         }
     }
-    if (a->n_updates < 1) return ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
     // adapted prediction on view 0 (ttl.py:350-352): layers below layer_lo are unchanged by the
     // update, so resume from the stream row block of view 0
-    return forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
+    if (a->n_updates < 1) rc = ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
+    else rc = forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
+    if (rc) return rc;
+    return episode_tail(c, a, a->logits1_out, s);
 }
 
 // ---- the episode as a HIP graph: ~130 launches replayed with one hipGraphLaunch (the enqueue costs the host ~2.7 ms
@@ -1263,8 +1281,7 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     if (v->E != c->E) return fail(TTL_EINVAL, "embed dims differ (%d vs %d)", v->E, c->E);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    HIP_TRY(launch_lora_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, s));
-    HIP_TRY(launch_scaler_reset_step(c->sc, s));
+    HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s));
     // image side: forward only; its own logits (against whatever peer features it holds) are not used
     float* feats = v->head_te;   // [max_views, E] scratch of the image context
     if ((rc = forward_impl(v, a->x, a->n_views, 0, 0, nullptr, feats, stream))) return rc;
@@ -1277,22 +1294,20 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
             Prof p(c, 5, s);
             HIP_TRY(launch_entropy_loss(c->logits_nk, N, K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf,
-                                        c->dlogits_nk, c->loss_scratch, s));
+                                        c->dlogits_nk, c->loss_scratch, s, nullptr, c->sc.i + SC_FOUND_INF));
             HIP_TRY(launch_transpose_f32(c->dlogits_nk, N, K, c->dlogits_kn, s));
         }
-        if ((rc = backward_impl(c, c->dlogits_kn, K, stream))) return rc;
+        if ((rc = backward_impl(c, c->dlogits_kn, K, stream, true))) return rc;
         {
             Prof p(c, 5, s);
-            HIP_TRY(launch_scaler_pre_step(c->sc, c->n_buf, 0, a->beta1, a->beta2, c->sc_dynamic, c->sc_growth, c->sc_backoff,
-                                           c->sc_interval, s));
-            HIP_TRY(launch_adamw_dev(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                     a->weight_decay, c->sc, s));
+            HIP_TRY(launch_adamw_fused(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
+                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s));
         }
     }
     // adapted prediction on view 0: new text features (layers below layer_lo unchanged -> resume), row 0 of the logits
     if ((rc = forward_impl(c, nullptr, K, 0, a->n_updates < 1 ? 0 : c->c.layer_lo, nullptr, nullptr, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(a->logits1_out, c->logits_nk, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return 0;
+    return episode_tail(c, a, a->logits1_out, s);
 }
 
 // ------------------------------------------------------------------------------ kernel-level entry points

@@ -218,7 +218,7 @@ static void head_extent(const HeadArgs& a, int n) {
     span_r(a.ln_g, (size_t)a.D * 4); span_r(a.ln_b, (size_t)a.D * 4);
     span_r(a.WpT, (size_t)a.D * a.E * 4); span_r(a.Wp, (size_t)a.D * a.E * 4);
     if (a.K > 0) { span_r(a.tfeat, (size_t)a.K * a.E * 4); span_r(a.tfeatT, (size_t)a.K * a.E * 4); }
-    span_w(a.cls_mean, (size_t)n * 4); span_w(a.cls_rstd, (size_t)n * 4); span_w(a.y, (size_t)n * a.D * 4); span_w(a.f, (size_t)n * a.E * 4);
+    span_w(a.cls_mean, (size_t)n * 4); span_w(a.cls_rstd, (size_t)n * 4); span_w(a.f, (size_t)n * a.E * 4);
 }
 hipError_t launch_head_fwd(const HeadArgs& a, int n, hipStream_t) {
     head_extent(a, n);
@@ -231,14 +231,15 @@ hipError_t launch_head_logits(const HeadArgs& a, int n, hipStream_t) {
     return hipSuccess;
 }
 hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls, op_t* dcls_bf16, int n, hipStream_t) {
-    span_r(dlogits, (size_t)n * a.K * 4); span_r(a.f, (size_t)n * a.E * 4); span_r(a.y, (size_t)n * a.D * 4);
+    span_r(dlogits, (size_t)n * a.K * 4); span_r(a.f, (size_t)n * a.E * 4);
     span_w(a.tmp_e, (size_t)n * a.E * 4); span_w(a.tmp_d, (size_t)n * a.D * 4);
     span_w(dcls, (size_t)n * a.D * 4); span_w(dcls_bf16, (size_t)n * a.D * 2);
     if (a.gscale) span_r(a.gscale, 4);
     return hipSuccess;
 }
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int, int, double, float, float, float, int, float* H_out, long long* idx_io,
-                               int* n_io, float* loss_out, float* dlogits, float* scratch, hipStream_t, const unsigned char* keep) {
+                               int* n_io, float* loss_out, float* dlogits, float* scratch, hipStream_t, const unsigned char* keep, int* clear_flag) {
+    if (clear_flag) *clear_flag = 0;
     span_r(logits, (size_t)N * K * 4); span_w(dlogits, (size_t)N * K * 4); span_w(scratch, ((size_t)4 * N + 3 * K + 16) * 4);
     span_w(H_out, (size_t)N * 4); span_w(idx_io, (size_t)N * 8); span_w(loss_out, 4); if (keep) span_r(keep, N);
     if (n_io) *n_io = N;      // "every view selected": the optimizer step below runs
@@ -254,6 +255,19 @@ hipError_t launch_scaler_pre_step(ScalerState st, const int* nsel, int, float, f
 }
 hipError_t launch_adamw_dev(float* p, const float* g, float* m, float* v, size_t n, float, float, float, float, float, ScalerState st, hipStream_t) {
     span_w(p, n * 4); span_r(g, n * 4); span_w(m, n * 4); span_w(v, n * 4); span_r(st.f, SC_NF * 4); span_r(st.i, SC_NI * 4);
+    return hipSuccess;
+}
+hipError_t launch_adamw_fused(float* p, const float* g, float* m, float* v, size_t n, float, float, float, float, float, ScalerState st, const int* nsel,
+                              int, int, float, float, int, hipStream_t) {
+    span_w(p, n * 4); span_r(g, n * 4); span_w(m, n * 4); span_w(v, n * 4); span_w(st.f, SC_NF * 4); span_w(st.i, SC_NI * 4); if (nsel) span_r(nsel, 4);
+    return hipSuccess;
+}
+hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t) {
+    memcpy(p, snap, n * 4); memset(m, 0, n * 4); memset(v, 0, n * 4); span_w(st.i, SC_NI * 4);
+    return hipSuccess;
+}
+hipError_t launch_topk_hits(const float* logits, int K, const long long* target, long long* hits, hipStream_t) {
+    span_r(logits, (size_t)K * 4); span_r(target, 8); span_w(hits, 24);
     return hipSuccess;
 }
 hipError_t launch_scaler_unscale(float* g, size_t n, ScalerState st, hipStream_t) { span_w(g, n * 4); span_r(st.f, SC_NF * 4); span_w(st.i, 4); return hipSuccess; }

@@ -176,7 +176,8 @@ hipError_t launch_head_bwd(const HeadArgs& a, const float* dlogits, float* dcls,
 hipError_t launch_entropy_loss(const float* logits, int N, int K, int objective, int mode, double rho, float thresh,
                                float margin, float reweight, int reuse_idx, float* H_out, long long* idx_io,
                                int* n_io, float* loss_out, float* dlogits, float* scratch /*>= 4*N + 3*K + 16 floats*/,
-                               hipStream_t s, const unsigned char* keep = nullptr);
+                               hipStream_t s, const unsigned char* keep = nullptr,
+                               int* clear_flag = nullptr /* != null: *clear_flag = 0 on the way (ScalerState found_inf before the backward) */);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                         float eps, float wd, int step, const int* n_selected, hipStream_t s);
 // ---- torch.amp.GradScaler semantics (ttl.py:222, deyo.py:186-188) with the state on the device, so that a whole
@@ -185,7 +186,8 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
 // i[3] do_step (decision of the current update), i[4] steps skipped on inf/nan so far.
 struct ScalerState { float* f; int* i; };
 enum { SC_SCALE = 0, SC_INV = 1, SC_BC1 = 2, SC_BC2S = 3, SC_NF = 4 };
-enum { SC_FOUND_INF = 0, SC_TRACKER = 1, SC_STEP = 2, SC_DO_STEP = 3, SC_SKIPPED = 4, SC_NI = 8 };
+// i[5] / i[6]: the step count again, in two slots the fused optimizer launch alternates between (adamw_fused_kernel)
+enum { SC_FOUND_INF = 0, SC_TRACKER = 1, SC_STEP = 2, SC_DO_STEP = 3, SC_SKIPPED = 4, SC_STEP_A = 5, SC_STEP_B = 6, SC_NI = 8 };
 // scaler.step + scaler.update decision of one update (one thread): nothing at all when *n_selected == 0 (deyo.py:183);
 // found_inf -> skip the WHOLE step, scale *= backoff, tracker = 0; else step (host_step > 0: that step count, else the
 // device counter + 1), tracker += 1, scale *= growth every `interval` clean steps.  Clears found_inf.
@@ -197,6 +199,15 @@ hipError_t launch_adamw_dev(float* p, const float* g, float* m, float* v, size_t
 // scaler.unscale_(optimizer) on an arbitrary gradient buffer: g *= 1/scale, found_inf |= any non-finite
 hipError_t launch_scaler_unscale(float* g, size_t n, ScalerState st, hipStream_t s);
 hipError_t launch_scaler_reset_step(ScalerState st, hipStream_t s);
+// The fused episode's forms (one launch each): launch_scaler_pre_step + launch_adamw_dev with the step count read from slot
+// `parity` & 1 and written to the other slot (update u of an episode passes u; launch_episode_reset zeroes both slots);
+// launch_lora_reset (m, v required) + launch_scaler_reset_step.
+hipError_t launch_adamw_fused(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                              ScalerState st, const int* n_selected, int parity, int dynamic, float growth, float backoff, int interval,
+                              hipStream_t s);
+hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t s);
+// utils/tools.py:88-102 accuracy(output, target, (1, 5)) for one prediction row [1,K]: hits[0..2] += {top-1 hit, top-5 hit, 1}
+hipError_t launch_topk_hits(const float* logits, int K, const long long* target, long long* hits, hipStream_t s);
 hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- LoRA (lora.hip)

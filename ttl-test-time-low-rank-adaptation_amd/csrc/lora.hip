@@ -218,13 +218,21 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
 #ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no big skinny products, bit 1 = no wgrad
     { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && M >= 4096 && diag_skip_now(cnt, 360)) return hipSuccess; }
 #endif
-    const int3 xo = {xoff[0], ntg > 1 ? xoff[1] : 0, ntg > 2 ? xoff[2] : 0};
-    const int ncg = r / 16, ks = D / 32;
+    int3 xo = {xoff[0], ntg > 1 ? xoff[1] : 0, ntg > 2 ? xoff[2] : 0};
+    int ncg = r / 16;
+    const int ks = D / 32;
+    // Adapters that read the SAME columns of X (the forward's down-projections U_t = s x A_t^T of q / k / v: every xoff 0) are one
+    // product with ntg * r output columns: X is read once instead of once per adapter (19.4 MB per adapter at 64 views), the
+    // stacked rows of Wcat already lie behind each other, and the output columns k*r + c come out in place.
+    if (ntg > 1 && xo.y == xo.x && (ntg < 3 || xo.z == xo.x) && 16 * ntg * ncg * (D * 2 + 16) <= 150 * 1024) {
+        ncg *= ntg;
+        ntg = 1;
+    }
 #define SK(N_, K_) if (ncg == N_ && ks == K_ && D % 32 == 0) return skinny_launch<N_, K_>(X, ldx, xo, ntg, Wcat, D, scale, out, ldo, M, s, rowmap)
-    SK(1, 24); SK(2, 24);      // ViT-B/16, r = 16 / 32
-    SK(1, 32); SK(2, 32);      // ViT-L/14
-    SK(1, 16); SK(2, 16);      // text tower of ViT-B/16 (D = 512)
-    SK(1, 4);  SK(2, 4);       // reduced test geometry (D = 128)
+    SK(1, 24); SK(2, 24); SK(3, 24); SK(4, 24); SK(6, 24);      // ViT-B/16, r = 16 / 32 (x 1-3 adapters on the same X)
+    SK(1, 32); SK(2, 32); SK(3, 32); SK(4, 32);                 // ViT-L/14 (6 x 16 rows of D = 1024 do not fit the LDS: two passes)
+    SK(1, 16); SK(2, 16); SK(3, 16); SK(4, 16); SK(6, 16);      // text tower of ViT-B/16 (D = 512)
+    SK(1, 4);  SK(2, 4); SK(3, 4); SK(4, 4); SK(6, 4);          // reduced test geometry (D = 128)
 #undef SK
     return hipErrorInvalidValue;
 }

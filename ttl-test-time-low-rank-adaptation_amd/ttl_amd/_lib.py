@@ -45,7 +45,7 @@ class ttl_episode_args(C.Structure):
                 ("reweight", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("snapshot", C.c_void_p),
                 ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("logits0_out", C.c_void_p),
-                ("logits1_out", C.c_void_p)]
+                ("logits1_out", C.c_void_p), ("target", C.c_void_p), ("hits_out", C.c_void_p)]
 
 
 _P, _I, _F, _D, _Z = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t

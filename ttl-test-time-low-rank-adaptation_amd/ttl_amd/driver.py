@@ -429,48 +429,56 @@ class EpisodePipeline:
         self._next = 0
         torch.cuda.synchronize(self.slots[0]["flat"].device)
 
-    def submit(self, views, target=None, persistent_input=False, **episode_kw):
-        """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K].
-        With ``target`` (device int64 [1]) the slot's [hits1, hits5, count] accumulator is updated on
-        the same stream (no host sync).  The caller must not overwrite ``views`` until the slot's
-        stream has caught up.  ``persistent_input`` (graph replay only): ``views`` is a buffer the caller keeps alive and
-        re-submits (bench.py's pre-staged batches) — the slot captures one graph per such buffer and replays it in place,
-        instead of copying every batch into the slot's own input buffer first (38.5 MB per image at 64 views)."""
+    def submit(self, views, target=None, persistent_input=False, want_output=True, **episode_kw):
+        """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K] (None with
+        ``want_output=False``: the caller only wants the accuracy accumulator — bench.py — and no copy is made).
+        With ``target`` (device int64 [1]) the slot's [hits1, hits5, count] accumulator is updated INSIDE the episode's enqueue
+        (ttl_episode_args.target / hits_out: one hit-count launch of the library, utils/tools.py:88-102 semantics; no torch
+        kernel runs on the hot path and nothing synchronises).  The caller must not overwrite ``views`` / ``target`` until the
+        slot's stream has caught up.  ``persistent_input`` (graph replay only): ``views`` and ``target`` are buffers the caller
+        keeps alive and re-submits (bench.py's pre-staged batches) — the slot captures one graph per such (views, target) pair and
+        replays it in place, instead of copying every batch into the slot's own input buffer first (38.5 MB per image at 64 views)."""
         sl = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         sl["stream"].wait_stream(torch.cuda.current_stream())
         views.record_stream(sl["stream"])          # the caching allocator must not recycle it under the slot's stream
+        hits = sl["acc"] if target is not None else None
         if target is not None:
+            assert target.dtype == torch.int64 and target.is_cuda
             target.record_stream(sl["stream"])
         with torch.cuda.stream(sl["stream"]):
             if self.use_graph:
-                key = (tuple(views.shape), tuple(sorted(episode_kw.items())))
+                key = (tuple(views.shape), target is not None, tuple(sorted(episode_kw.items())))
                 if sl.get("gkey") != key:          # another shape / argument set: every captured graph of the slot is stale
                     sl["gkey"], sl["graph"], sl["xbuf"], sl["graphs_in_place"] = key, None, None, {}
                     sl["obuf"] = torch.empty((1, sl["eng"].n_classes), dtype=torch.float32, device=views.device)
+                    sl["tbuf"] = torch.zeros(1, dtype=torch.int64, device=views.device) if target is not None else None
                 inplace = sl["graphs_in_place"]
-                if persistent_input and (views.data_ptr() in inplace or len(inplace) < 16):
-                    g = inplace.get(views.data_ptr())
-                    if g is None:                   # (the capture runs this episode already)
-                        g = inplace[views.data_ptr()] = (sl["eng"].episode_graph(views, sl["snap"], sl["m"], sl["v"], sl["obuf"], **episode_kw), views)
-                        out = sl["obuf"].clone()
+                pkey = (views.data_ptr(), target.data_ptr() if target is not None else 0)
+                if persistent_input and (pkey in inplace or len(inplace) < 16):
+                    g = inplace.get(pkey)
+                    if g is None:                   # (the capture runs this episode already: its hit is counted)
+                        g = inplace[pkey] = (sl["eng"].episode_graph(views, sl["snap"], sl["m"], sl["v"], sl["obuf"], target=target,
+                                                                     hits=hits, **episode_kw), views, target)
                     else:
-                        out = g[0]().clone()
+                        g[0]()
                 elif sl["graph"] is None:
                     sl["xbuf"] = torch.empty_like(views)
                     sl["xbuf"].copy_(views)
-                    sl["graph"] = sl["eng"].episode_graph(sl["xbuf"], sl["snap"], sl["m"], sl["v"], sl["obuf"], **episode_kw)
-                    out = sl["obuf"].clone()          # the capture ran this episode already
+                    if target is not None:
+                        sl["tbuf"].copy_(target.reshape(-1)[:1])
+                    sl["graph"] = sl["eng"].episode_graph(sl["xbuf"], sl["snap"], sl["m"], sl["v"], sl["obuf"], target=sl["tbuf"],
+                                                          hits=hits, **episode_kw)      # the capture ran this episode already
                 else:
                     sl["xbuf"].copy_(views, non_blocking=True)
-                    out = sl["graph"]().clone()       # obuf is overwritten by the slot's next episode
+                    if target is not None:
+                        sl["tbuf"].copy_(target.reshape(-1)[:1], non_blocking=True)
+                    sl["graph"]()
+                out = sl["obuf"].clone() if want_output else None       # obuf is overwritten by the slot's next episode
             else:
-                out = sl["eng"].episode(views, sl["snap"], sl["m"], sl["v"], **episode_kw)
-            if target is not None:
-                h1, h5 = topk_hits(out, target)
-                sl["acc"][0] += h1
-                sl["acc"][1] += h5
-                sl["acc"][2] += 1
+                out = sl["eng"].episode(views, sl["snap"], sl["m"], sl["v"], target=target, hits=hits, **episode_kw)
+                if not want_output:
+                    out = None
         return out
 
     def synchronize(self):

@@ -249,13 +249,15 @@ class TTLEngine:
 
     def episode(self, x, snapshot, m, v, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH, rho=0.1,
                 thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                want_logits0=False):
-        """One whole test image (ttl.py:338-352) as a single enqueue; returns logits1 [1,K] (and logits0)."""
+                want_logits0=False, target=None, hits=None, out=None):
+        """One whole test image (ttl.py:338-352) as a single enqueue; returns logits1 [1,K] (and logits0).
+        target (device int64 [1]) + hits (device int64 [3]): top-1 / top-5 hit of the adapted prediction and the image count are
+        added to ``hits`` on the device (utils/tools.py:88-102), inside the same enqueue.  out: write logits1 there ([1,K])."""
         import math
         self._skipped_seen = None            # a fused episode may skip steps of its own: step_was_taken() re-reads its baseline
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         n = x.shape[0]
-        l1 = torch.empty((1, self.n_classes), dtype=torch.float32, device=self.device)
+        l1 = out if out is not None else torch.empty((1, self.n_classes), dtype=torch.float32, device=self.device)
         l0 = torch.empty((n, self.n_classes), dtype=torch.float32, device=self.device) if want_logits0 else None
         a = _lib.ttl_episode_args()
         a.x, a.n_views, a.n_updates = x.data_ptr(), n, int(n_updates)
@@ -267,15 +269,26 @@ class TTLEngine:
         a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
         a.logits0_out = l0.data_ptr() if want_logits0 else None
         a.logits1_out = l1.data_ptr()
+        self._set_target(a, target, hits)
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
         return (l1, l0) if want_logits0 else l1
 
+    def _set_target(self, a, target, hits):
+        if (target is None) != (hits is None):
+            raise _lib.TtlError("target and hits go together")
+        if target is not None:
+            assert target.is_cuda and target.dtype == torch.int64 and target.numel() >= 1 and target.is_contiguous()
+            assert hits.is_cuda and hits.dtype == torch.int64 and hits.numel() >= 3 and hits.is_contiguous()
+            a.target, a.hits_out = target.data_ptr(), hits.data_ptr()
+
     def episode_graph(self, x_buf, snapshot, m, v, logits1_buf, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH,
-                      rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        """Capture the episode over FIXED buffers (x_buf [N,3,S,S], logits1_buf [1,K], snapshot / m / v) into a HIP
-        graph on the current (non-default) stream; returns a callable that replays it on the current stream.  The
-        capture itself runs the episode once on whatever x_buf holds."""
+                      rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                      target=None, hits=None):
+        """Capture the episode over FIXED buffers (x_buf [N,3,S,S], logits1_buf [1,K], snapshot / m / v, and — for the on-device
+        hit count — target int64 [1] / hits int64 [3]) into a HIP graph on the current (non-default) stream; returns a callable
+        that replays it on the current stream.  The capture itself runs the episode once on whatever the buffers hold (that run
+        counts into ``hits`` like any other)."""
         import math
         assert x_buf.is_cuda and x_buf.is_contiguous() and logits1_buf.is_contiguous()
         a = _lib.ttl_episode_args()
@@ -287,12 +300,13 @@ class TTLEngine:
         a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, betas[0], betas[1], eps, weight_decay
         a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
         a.logits0_out, a.logits1_out = None, logits1_buf.data_ptr()
+        self._set_target(a, target, hits)
         g = C.c_void_p()
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode_capture(self._h, C.byref(a), _stream(), C.byref(g)))
         self._graphs = getattr(self, "_graphs", [])
         self._graphs.append(g)
-        keep = (x_buf, snapshot, m, v, logits1_buf)     # the graph holds raw pointers into these
+        keep = (x_buf, snapshot, m, v, logits1_buf, target, hits)     # the graph holds raw pointers into these
 
         def launch(_keep=keep):
             with torch.cuda.device(self.device):
@@ -383,7 +397,7 @@ class TextTowerEngine(TTLEngine):
 
     def episode(self, image_engine: TTLEngine, x, snapshot, m, v, *, n_updates=1, objective="deyo",
                 mode=_lib.TTL_SEL_LE_THRESH, rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999),
-                eps=1e-8, weight_decay=1e-2, want_logits0=False):
+                eps=1e-8, weight_decay=1e-2, want_logits0=False, target=None, hits=None):
         """Whole text-mode episode as one enqueue; ``image_engine`` is an adapter-less image-tower engine."""
         import math
         self._skipped_seen = None
@@ -401,6 +415,7 @@ class TextTowerEngine(TTLEngine):
         a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
         a.logits0_out = l0.data_ptr() if want_logits0 else None
         a.logits1_out = l1.data_ptr()
+        self._set_target(a, target, hits)
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode_text(self._h, image_engine._h, C.byref(a), _stream()))
         self.n_views = n
