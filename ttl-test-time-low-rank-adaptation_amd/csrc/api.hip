@@ -649,6 +649,22 @@ static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* l
     return a;
 }
 
+// where the fused reset / optimizer launches write the operand-dtype images of the bound LoRA parameters (lora_refresh's outputs)
+static bool lora_images(ttl_ctx* c, LoraImages* im) {
+    memset(im, 0, sizeof *im);
+    if (!c->lora_p || c->nT > LORA_IMG_MAX_LAYERS) return false;
+    im->layers = c->nT; im->ntg = c->ntg; im->D = c->D; im->r = c->r; im->ldw = c->ldw; im->ldwt = c->ldwt;
+    int k = 0;
+    for (int t = 0; t < 4; ++t)
+        if (c->tg & (1 << t)) im->proj[k++] = t;
+    for (int i = 0; i < c->nT; ++i) {
+        Layer& l = c->layers[c->c.layer_lo + i];
+        im->ldwo = l.ldwo;
+        im->L[i] = {l.wqkv, l.wqkvT, l.acat, l.btcat, l.wo, l.woT, l.acat_o, l.btcat_o};
+    }
+    return true;
+}
+
 static int lora_refresh(ttl_ctx* c, hipStream_t s) {
     if (!c->lora_p) return 0;
     Prof p(c, 4, s);
@@ -671,8 +687,9 @@ static int lora_refresh(ttl_ctx* c, hipStream_t s) {
 // frozen layers below it do not depend on the LoRA parameters, so for the same views the result
 // is identical — used for the later updates of a multi-step episode and for the adapted
 // inference on view 0 (rows 0..T-1 of that buffer).
+// images_fresh: the caller's last launch on this stream (the fused episode's reset / optimizer) has already written the LoRA images
 static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_layer, float* logits_out, float* feats_out,
-                        void* stream) {
+                        void* stream, bool images_fresh = false) {
     if (!c || (!x && from_layer == 0 && !c->text)) return fail(TTL_EINVAL, "null argument");
     if (n < 1 || n > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", n, c->c.max_views);
     if (c->K < 1 && (logits_out || save))   // a features-only forward needs no peer features
@@ -684,7 +701,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H;
-    if ((rc = lora_refresh(c, s))) return rc;
+    if (!images_fresh && (rc = lora_refresh(c, s))) return rc;
     float* h = c->h;
     if (from_layer == 0 && c->text) {
         Prof p(c, 3, s);
@@ -1200,13 +1217,15 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    LoraImages im;
+    const bool fresh = lora_images(c, &im);     // reset and optimizer launches keep the operand-dtype LoRA images current themselves
     {
         Prof p(c, 5, s);   // LoRA_AB.reset + optimizer.load_state_dict(empty): step count 0; the loss scale PERSISTS (Q14)
-        HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s));
+        HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s, fresh ? &im : nullptr));
     }
     for (int u = 0; u < a->n_updates; ++u) {
         if ((rc = forward_impl(c, a->x, a->n_views, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr,
-                               stream)))
+                               stream, fresh)))
             return rc;
         {
             Prof p(c, 5, s);
@@ -1218,13 +1237,14 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
         {
             Prof p(c, 5, s);   // scaler.step(optimizer); scaler.update()  (deyo.py:186-188): whole step or nothing
             HIP_TRY(launch_adamw_fused(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s));
+                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s,
+                                       fresh ? &im : nullptr));
         }
     }
     // adapted prediction on view 0 (ttl.py:350-352): layers below layer_lo are unchanged by the
     // update, so resume from the stream row block of view 0
-    if (a->n_updates < 1) rc = ttl_vit_forward(c, a->x, 1, 0, a->logits1_out, nullptr, stream);
-    else rc = forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream);
+    if (a->n_updates < 1) rc = forward_impl(c, a->x, 1, 0, 0, a->logits1_out, nullptr, stream, fresh);
+    else rc = forward_impl(c, a->x, 1, 0, c->c.layer_lo, a->logits1_out, nullptr, stream, fresh);
     if (rc) return rc;
     return episode_tail(c, a, a->logits1_out, s);
 }
@@ -1281,14 +1301,16 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     if (v->E != c->E) return fail(TTL_EINVAL, "embed dims differ (%d vs %d)", v->E, c->E);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s));
+    LoraImages im;
+    const bool fresh = lora_images(c, &im);
+    HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s, fresh ? &im : nullptr));
     // image side: forward only; its own logits (against whatever peer features it holds) are not used
     float* feats = v->head_te;   // [max_views, E] scratch of the image context
     if ((rc = forward_impl(v, a->x, a->n_views, 0, 0, nullptr, feats, stream))) return rc;
     if ((rc = set_peer_features(c, feats, a->n_views, 1, c->scale, s))) return rc;
     const int N = a->n_views, K = c->n_prompts;
     for (int u = 0; u < a->n_updates; ++u) {
-        if ((rc = forward_impl(c, nullptr, K, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr, stream)))
+        if ((rc = forward_impl(c, nullptr, K, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr, stream, fresh)))
             return rc;
         {
             Prof p(c, 5, s);
@@ -1301,11 +1323,12 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
         {
             Prof p(c, 5, s);
             HIP_TRY(launch_adamw_fused(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,
-                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s));
+                                       a->weight_decay, c->sc, c->n_buf, u, c->sc_dynamic, c->sc_growth, c->sc_backoff, c->sc_interval, s,
+                                       fresh ? &im : nullptr));
         }
     }
     // adapted prediction on view 0: new text features (layers below layer_lo unchanged -> resume), row 0 of the logits
-    if ((rc = forward_impl(c, nullptr, K, 0, a->n_updates < 1 ? 0 : c->c.layer_lo, nullptr, nullptr, stream))) return rc;
+    if ((rc = forward_impl(c, nullptr, K, 0, a->n_updates < 1 ? 0 : c->c.layer_lo, nullptr, nullptr, stream, fresh))) return rc;
     HIP_TRY(hipMemcpyAsync(a->logits1_out, c->logits_nk, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
     return episode_tail(c, a, a->logits1_out, s);
 }

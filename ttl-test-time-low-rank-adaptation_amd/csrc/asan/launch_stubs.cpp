@@ -257,12 +257,32 @@ hipError_t launch_adamw_dev(float* p, const float* g, float* m, float* v, size_t
     span_w(p, n * 4); span_r(g, n * 4); span_w(m, n * 4); span_w(v, n * 4); span_r(st.f, SC_NF * 4); span_r(st.i, SC_NI * 4);
     return hipSuccess;
 }
+// the images the fused reset / optimizer launches write element by element: the same extents the refresh stub touches
+static void lora_image_extents(const LoraImages* im) {
+    if (!im || im->layers <= 0) return;
+    const size_t D = im->D, r = im->r;
+    int nqkv = 0, has_o = 0;
+    for (int k = 0; k < im->ntg; ++k) { if (im->proj[k] < 3) ++nqkv; else has_o = 1; }
+    for (int i = 0; i < im->layers; ++i) {
+        const LoraLayerImages& L = im->L[i];
+        if (nqkv) {
+            mat_w(L.wext, 3 * D, D + nqkv * r, im->ldw, 2); mat_w(L.wtext, D, 3 * D + nqkv * r, im->ldwt, 2);
+            span_w(L.acat, nqkv * r * D * 2); span_w(L.btcat, nqkv * r * D * 2);
+        }
+        if (has_o) {
+            mat_w(L.woext, D, D + r, im->ldwo, 2); mat_w(L.wotext, D, D + r, im->ldwo, 2);
+            span_w(L.acat_o, r * D * 2); span_w(L.btcat_o, r * D * 2);
+        }
+    }
+}
 hipError_t launch_adamw_fused(float* p, const float* g, float* m, float* v, size_t n, float, float, float, float, float, ScalerState st, const int* nsel,
-                              int, int, float, float, int, hipStream_t) {
+                              int, int, float, float, int, hipStream_t, const LoraImages* im) {
+    lora_image_extents(im);
     span_w(p, n * 4); span_r(g, n * 4); span_w(m, n * 4); span_w(v, n * 4); span_w(st.f, SC_NF * 4); span_w(st.i, SC_NI * 4); if (nsel) span_r(nsel, 4);
     return hipSuccess;
 }
-hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t) {
+hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t, const LoraImages* im) {
+    lora_image_extents(im);
     memcpy(p, snap, n * 4); memset(m, 0, n * 4); memset(v, 0, n * 4); span_w(st.i, SC_NI * 4);
     return hipSuccess;
 }

@@ -78,8 +78,31 @@ __device__ __forceinline__ opx8 acc_frag(const f32x16& a, int s) {
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// store a [64 x 32] transposed accumulator pair (rows = head-dim, column = this lane's token)
+// store a [64 x 32] transposed accumulator pair (rows = head-dim, column = this lane's token).
+// A lane holds 4 consecutive head-dim values (8 B) of its token per register group g; the other half-wave holds the NEXT 8 B of the
+// same token.  v_permlane32_swap between groups g and g+1 gives the lower half-wave 16 contiguous bytes of group g and the upper one
+// 16 contiguous bytes of group g+1 (guide T21): 4 x 16-B stores per lane instead of 8 x 8-B, each instruction still one piece per
+// token row, so half the row-line visits on the store path (the per-token pieces are 1.5 KB apart: a store instruction touches
+// 32 lines whatever its width).  Both lanes of a pair belong to the same token: they are masked together.
+#ifndef TTL_ATTN_WIDE_STORE
+#define TTL_ATTN_WIDE_STORE 1
+#endif
 __device__ __forceinline__ void store_ot(op_t* dst_row, const f32x16 (&o)[2], float mul, int lane) {
+#if TTL_ATTN_WIDE_STORE
+    const int up = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            uint32_t a0 = pack_op2(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul), a1 = pack_op2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul);
+            uint32_t b0 = pack_op2(o[dt][4 * g + 4] * mul, o[dt][4 * g + 5] * mul), b1 = pack_op2(o[dt][4 * g + 6] * mul, o[dt][4 * g + 7] * mul);
+            // vdst = group g, src = group g+1: lanes 32-63 of vdst <-> lanes 0-31 of src
+            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            // lower half: [own g | upper's g] = dims 8g .. 8g+7;  upper half: [lower's g+1 | own g+1] = dims 8(g+1) .. 8(g+1)+7
+            *(u32x4*)(dst_row + 32 * dt + 8 * (g + up)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+#else
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -88,6 +111,7 @@ __device__ __forceinline__ void store_ot(op_t* dst_row, const f32x16 (&o)[2], fl
             *(u32x2*)(dst_row + dh) = u32x2{pack_op2(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul),
                                             pack_op2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
         }
+#endif
 }
 
 constexpr float SCALE = 0.125f;  // head_dim^-0.5, head_dim = 64
@@ -313,7 +337,7 @@ __device__ __forceinline__ void dma16_untracked(const void* g, const char* lds) 
 // the views whose q/k/v rows XCD x's tiles of the QKV GEMM have just written (producer / consumer on the same L2): no change either.
 template <int NKT, int CH>
 __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out,
-                                                             int ldo, float* __restrict__ lse, int T, int H, int nprob) {
+                                                             int ldo, float* __restrict__ lse, int T, int H, int nprob, int xmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKT * 32, NTHR = 64 * NKT, TILE = TP * 128, BUF = 2 * TILE, QOFF = 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -355,7 +379,16 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
         }
     };
     const int q = wave * 32 + l31;
-    int p = blockIdx.x;
+    // xmap (TTL_ATTN_XCD_MAP=1, experiment): blocks b, b+8, ... share an XCD (round-robin dispatch); XCD x then walks the problems of
+    // views [x n/8, (x+1) n/8) — the rows whose out_proj tiles the big-M GEMM gives to XCD x (gemm_big.hip tile_of) — so that the
+    // attention output is still in the L2 that reads it as the next launch's A operand.  p_step / p_end describe the block's walk.
+    int p = blockIdx.x, p_step = gridDim.x, p_end = nprob;
+    if (xmap && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const int lo = (int)((long long)x * nprob / 8), hi = (int)((long long)(x + 1) * nprob / 8);
+        p = lo + j; p_step = nb; p_end = hi;
+        if (p >= p_end) return;
+    }
     int img = p / H, head = p - img * H;
     stage(qkv + (size_t)img * L.view + (size_t)head * L.head, smem);
 
@@ -373,8 +406,8 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const opx8*)(smem + QOFF + 32 * wave * 128 + koff[ks]);
         // next problem: K/V into the other half of the LDS (everyone is past the barrier, so nobody reads that half any
         // more), q over this wave's own rows once they are in registers
-        const int pn = p + gridDim.x;
-        const bool more = pn < nprob;
+        const int pn = p + p_step;
+        const bool more = pn < p_end;
         int imgn = img, headn = head;
         if (more) {
             imgn = pn / H; headn = pn - imgn * H;
@@ -458,7 +491,191 @@ __global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_p_kernel(const op_t* __r
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));     // next problem's q/K/V landed (see the loop top)
         __builtin_amdgcn_sched_barrier(0);
-        if (q < T) {
+        if (TTL_ATTN_DIAG == 3) {       // timing-only: no output stores (accumulators kept alive)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) asm volatile("" ::"v"(o[dt]));
+            asm volatile("" ::"v"(l_run), "v"(m_run));
+        } else if (q < T) {
+            store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / l_run, lane);
+            if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = m_run * SCALE + __logf(l_run);
+        }
+        if (!more) break;
+        p = pn; img = imgn; head = headn;
+    }
+}
+
+// ------------------------------------------------------------------------------ forward, persistent + software-pipelined (round 4)
+// Same outer structure as attn_fwd_p_kernel (one workgroup per CU walks (view, head) problems, the next problem's q/K/V arrive by
+// LDS-DMA meanwhile), but the inner loop is a per-key-tile pipeline instead of three whole-row phases:
+//   iteration t:   S(t+1) = K(t+1) Q^T   (4 MFMAs, issued FIRST: they run on the matrix pipe ...)
+//                  softmax of S(t)        (... while the VALU forms P(t) = exp2(S(t) C2 - m C2), its row sum and the packed fragments)
+//                  O^T += V(t)^T P(t)^T   (4 MFMAs)
+// with the K fragments of tile t+2 and the V^T fragments of tile t+1 requested from LDS one iteration ahead.  attn_fwd_p_kernel
+// spends a problem as QK phase (every MFMA behind the LDS read it has just issued), a 56-deep v_max3 chain, an exp phase with a
+// 112-deep add chain, then PV: 14 k cycles per problem where the VALU issue floor of its own instruction mix is ~6 k.
+// Running maximum with a deferred rescale (guide T13): m only moves when a tile's maximum exceeds it by more than THR (in exp2
+// units), so after the first tile the 32-register rescale of O almost never runs; P stays <= 2^THR (relative precision of the
+// 16-bit P operand unchanged), l is summed in fp32, O / l and lse = m SCALE + log l come out as before up to fp32 rounding order.
+constexpr float ATTN_DEFER_THR = 4.0f;      // exp2 units: P <= 16
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT, 1) void attn_fwd_s_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out,
+                                                             int ldo, float* __restrict__ lse, int T, int H, int nprob) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKT * 32, NTHR = 64 * NKT, TILE = TP * 128, BUF = 2 * TILE, QOFF = 2 * BUF;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = L.tok;
+    const int h = lane >> 5, l31 = lane & 31;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + h) ^ swz(l31)) << 4);
+    int voff[2][2];
+    {
+        const int grp = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) voff[dt][hh] = TILE + tile_off(8 * hh + 4 * h + qq, 32 * dt + 16 * grp + 4 * pp);
+    }
+    auto stage = [&](const op_t* qg, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c16 = i * NTHR + tid, r = c16 >> 3, pz = c16 & 7;
+            const int c = pz ^ swz(r);
+            const size_t go = (size_t)min(r, T - 1) * ld + c * 8;
+            dma16_untracked(qg + L.k_off + go, buf + (i * NTHR + wave * 64) * 16);
+            dma16_untracked(qg + L.v_off + go, buf + TILE + (i * NTHR + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wave + 8 * i + (lane >> 3), c = (lane & 7) ^ swz(r);
+            dma16_untracked(qg + (size_t)min(r, T - 1) * ld + c * 8, smem + QOFF + (32 * wave + 8 * i) * 128);
+        }
+    };
+    const int q = wave * 32 + l31;
+    int p = blockIdx.x;
+    int img = p / H, head = p - img * H;
+    stage(qkv + (size_t)img * L.view + (size_t)head * L.head, smem);
+
+    constexpr float C2 = SCALE * 1.4426950408889634f;
+    constexpr float THR_RAW = ATTN_DEFER_THR / C2;       // the threshold in raw-score units
+    for (int it = 0;; ++it) {
+        const int boff = (it & 1) * BUF;
+        if (it == 0) __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        opx8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const opx8*)(smem + QOFF + 32 * wave * 128 + koff[ks]);
+        const int pn = p + gridDim.x;
+        const bool more = pn < nprob;
+        int imgn = img, headn = head;
+        if (more) {
+            imgn = pn / H; headn = pn - imgn * H;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (TTL_ATTN_DIAG != 2) stage(qkv + (size_t)imgn * L.view + (size_t)headn * L.head, smem + (boff ^ BUF));
+        }
+        const char* kbase = smem + boff;
+        auto load_k = [&](opx8 (&kf)[4], int kt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const opx8*)(kbase + koff[ks] + 32 * kt * 128);
+        };
+        auto load_v = [&](opx8 (&vf)[2][2], int kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int kbyte = (32 * kt + 16 * s2) * 128;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(kbase + voff[dt][0] + kbyte));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(kbase + voff[dt][1] + kbyte));
+                    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    vf[s2][dt] = __builtin_bit_cast(opx8, v);
+                }
+        };
+        auto qk = [&](const opx8 (&kf)[4]) {
+            f32x16 a = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a = MFMA32(kf[ks], qf[ks], a, 0, 0, 0);
+            return a;
+        };
+        opx8 kf[4], vf[2][2];
+        load_k(kf, 0);
+        f32x16 s_cur = qk(kf);
+        // max3f (inline asm) reads these registers: hipcc pads MFMA -> VALU hazards for its own instructions only (guide 5.7 item 2),
+        // so the wait states go INSIDE an asm statement that owns the tile.  Tiles kt >= 1 were multiplied a whole iteration earlier.
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_cur));
+        if (NKT > 1) load_k(kf, 1);
+        load_v(vf, 0);
+        float m_run = -INFINITY;
+        float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;       // four partial row sums: no 112-deep add chain
+        f32x16 o[2] = {};
+#pragma unroll
+        for (int kt = 0; kt < (TTL_ATTN_DIAG == 1 ? 0 : NKT); ++kt) {
+            f32x16 s_next = {};
+            if (kt + 1 < NKT) {
+                s_next = qk(kf);                             // tile kt+1 on the matrix pipe while the VALU does tile kt
+                if (kt + 2 < NKT) load_k(kf, kt + 2);
+            }
+            if (kt == NKT - 1 && 32 * NKT > T) {             // only the last key tile holds padded keys
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kt + acc_row(r, lane) >= T) s_cur[r] = -INFINITY;
+            }
+            // tile maximum: a tree of v_max3_f32, not a chain.  (fmaxf on MFMA outputs makes hipcc canonicalise every input with a
+            // v_max_f32 x, x first — 119 extra VALU instructions per problem here; the scores are never signalling NaNs.)
+            const float m0 = max3f(s_cur[0], s_cur[1], s_cur[2]), m1 = max3f(s_cur[3], s_cur[4], s_cur[5]);
+            const float m2 = max3f(s_cur[6], s_cur[7], s_cur[8]), m3 = max3f(s_cur[9], s_cur[10], s_cur[11]);
+            const float m4 = max3f(s_cur[12], s_cur[13], s_cur[14]);
+            float mx = max3f(max3f(m0, m1, m2), max3f(m3, m4, s_cur[15]), -INFINITY);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // the other half-wave holds the other 16 keys of this query
+            if (kt == 0) {
+                m_run = mx;
+            } else if (__any(mx > m_run + THR_RAW)) {        // wave-uniform and rare after the first tile
+                const float m_new = (mx > m_run + THR_RAW) ? mx : m_run;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C2);     // 1 for the lanes whose maximum did not move
+                m_run = m_new;
+                l0 *= alpha; l1 *= alpha; l2 *= alpha; l3 *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            const float mc = m_run * C2;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_cur[r], C2, -mc)), e1 = __builtin_amdgcn_exp2f(fmaf(s_cur[r + 1], C2, -mc));
+                const float e2 = __builtin_amdgcn_exp2f(fmaf(s_cur[r + 2], C2, -mc)), e3 = __builtin_amdgcn_exp2f(fmaf(s_cur[r + 3], C2, -mc));
+                s_cur[r] = e0; s_cur[r + 1] = e1; s_cur[r + 2] = e2; s_cur[r + 3] = e3;
+                l0 += e0; l1 += e1; l2 += e2; l3 += e3;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const opx8 pf = acc_frag(s_cur, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(vf[s2][dt], pf, o[dt], 0, 0, 0);
+            }
+            if (kt + 1 < NKT) load_v(vf, kt + 1);
+            s_cur = s_next;
+        }
+        float l_run = (l0 + l1) + (l2 + l3);
+        l_run += __shfl_xor(l_run, 32, 64);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | (0 << 14));     // next problem's q/K/V landed (see attn_fwd_p_kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        if (TTL_ATTN_DIAG == 3) {       // timing-only: no output stores (accumulators kept alive)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) asm volatile("" ::"v"(o[dt]));
+            asm volatile("" ::"v"(l_run), "v"(m_run));
+        } else if (q < T) {
             store_ot(out + (size_t)(img * T + q) * ldo + head * 64, o, 1.0f / l_run, lane);
             if (lse && lane < 32) lse[((size_t)img * H + head) * T + q] = m_run * SCALE + __logf(l_run);
         }
@@ -808,7 +1025,21 @@ hipError_t fwd_p(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, 
     if (!cus) return hipErrorInvalidDevice;
     const int nprob = n * H;
     const int grid = nprob < cus ? nprob : cus;
-    hipLaunchKernelGGL((attn_fwd_p_kernel<NKT, CH>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob);
+    static const int xmap = [] { const char* v = getenv("TTL_ATTN_XCD_MAP"); return v ? atoi(v) : 0; }();
+    hipLaunchKernelGGL((attn_fwd_p_kernel<NKT, CH>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob, xmap);
+    return hipGetLastError();
+}
+
+template <int NKT>
+hipError_t fwd_s(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, int n, int T, int H, hipStream_t s) {
+    constexpr int SMEM = 5 * NKT * 32 * 128;     // two (K, V) pairs + q
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_smem((const void*)attn_fwd_s_kernel<NKT>, SMEM, done); e != hipSuccess) return e;
+    const int cus = device_cu_count();
+    if (!cus) return hipErrorInvalidDevice;
+    const int nprob = n * H;
+    const int grid = nprob < cus ? nprob : cus;
+    hipLaunchKernelGGL((attn_fwd_s_kernel<NKT>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob);
     return hipGetLastError();
 }
 
@@ -865,6 +1096,8 @@ hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout ld_qkv, op_t* out, in
     if (nkt == 3) return fwd_w<3, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);   // text tower: T = 77
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     static const int variant = [] { const char* v = getenv("TTL_ATTN_VARIANT"); return v ? atoi(v) : 4; }();
+    if (variant == 5 && !causal && n * H >= 512 && nkt == 7)      // persistent + per-tile software pipeline (round 4)
+        return fwd_s<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     if (variant == 4 && !causal && n * H >= 512) {     // persistent, K/V of the next problem prefetched (big launches only)
         if (nkt == 7) return fwd_p<7, 7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);     // T = 257: five tiles of 36 KiB do not fit
     }

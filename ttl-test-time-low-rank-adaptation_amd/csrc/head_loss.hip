@@ -456,6 +456,21 @@ __global__ __launch_bounds__(256) void tpt_grad_kernel(const float* __restrict__
     }
 }
 
+// One AdamW element (torch.optim.AdamW, decoupled weight decay), the SAME instruction sequence in every kernel that steps: plain
+// IEEE fp32 operations, no fma contraction (hipcc contracts  b1*m + (1-b1)*g  one way or the other depending on the code around it,
+// which made the fused and the two-launch optimizer differ in the last bit from the second step on).
+__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd,
+                                            float bc1, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    const float pi = p * (1.0f - lr * wd);
+    const float mi = b1 * m + (1.0f - b1) * g;
+    const float vi = b2 * v + (1.0f - b2) * g * g;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    m = mi;
+    v = vi;
+    return pi - (lr / bc1) * (mi / denom);
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float bc2_sqrt, const int* __restrict__ nsel) {
@@ -464,11 +479,8 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     if (i >= n) return;
     float gi = g[i];
     if (!isfinite(gi)) return;       // GradScaler semantics: never step on inf/nan
-    float pi = p[i] * (1.0f - lr * wd);
-    float mi = b1 * m[i] + (1.0f - b1) * gi;
-    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    float mi = m[i], vi = v[i];
+    p[i] = adamw_elem(p[i], gi, mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
     m[i] = mi;
     v[i] = vi;
 }
@@ -499,12 +511,8 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float bc1 = st.f[SC_BC1], bc2_sqrt = st.f[SC_BC2S];
-    float gi = g[i];
-    float pi = p[i] * (1.0f - lr * wd);
-    float mi = b1 * m[i] + (1.0f - b1) * gi;
-    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    float mi = m[i], vi = v[i];
+    p[i] = adamw_elem(p[i], g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
     m[i] = mi;
     v[i] = vi;
 }
@@ -521,6 +529,43 @@ __global__ void scaler_reset_step_kernel(ScalerState st) {
     st.i[SC_STEP] = 0; st.i[SC_DO_STEP] = 0; st.i[SC_FOUND_INF] = 0; st.i[SC_STEP_A] = 0; st.i[SC_STEP_B] = 0;
 }
 
+// The operand-dtype images of LoRA element i of the flat buffer (what refresh_kernel, lora.hip, derives per layer): tensor
+// ti = i / (r D) — per layer A [r,D] then B [D,r] of every adapter slot — and the element's place in the K-extension columns of the
+// projection images and in the stacked A / B^T rows of the skinny products.
+__device__ __forceinline__ void write_lora_images(const LoraImages& im, size_t i, float val) {
+    const int per = im.r * im.D;
+    const int ti = (int)(i / per), w = (int)(i - (size_t)ti * per);
+    const int layer = ti / (2 * im.ntg), rem = ti - layer * 2 * im.ntg, slot = rem >> 1, isB = rem & 1;
+    if (layer >= im.layers) return;
+    const LoraLayerImages& L = im.L[layer];
+    const int t = im.proj[slot];
+    const op_t x = f32_to_op(val);
+    const int D = im.D, r = im.r;
+    if (t < 3) {
+        int k = 0;                      // position among the enabled q/k/v adapters
+        for (int s2 = 0; s2 < slot; ++s2) k += im.proj[s2] < 3;
+        if (isB) {
+            const int nB = w / r, jB = w - nB * r;
+            L.wext[(size_t)(t * D + nB) * im.ldw + D + k * r + jB] = x;
+            L.btcat[(size_t)(k * r + jB) * D + nB] = x;
+        } else {
+            const int jA = w / D, dA = w - jA * D;
+            L.acat[(size_t)(k * r + jA) * D + dA] = x;
+            L.wtext[(size_t)dA * im.ldwt + 3 * D + k * r + jA] = x;
+        }
+    } else {
+        if (isB) {
+            const int nB = w / r, jB = w - nB * r;
+            L.woext[(size_t)nB * im.ldwo + D + jB] = x;
+            L.btcat_o[(size_t)jB * D + nB] = x;
+        } else {
+            const int jA = w / D, dA = w - jA * D;
+            L.acat_o[(size_t)jA * D + dA] = x;
+            L.wotext[(size_t)dA * im.ldwo + D + jA] = x;
+        }
+    }
+}
+
 // ---- scaler.step(optimizer) + scaler.update() + AdamW in ONE launch (round 4; deyo.py:186-188, ttl.py:218).
 // Every block takes the GradScaler decision itself, from words NO block of this launch writes: found_inf (OR-ed by the backward's
 // gradient reduction, cleared again when the next loss is formed), *nsel, and the step count of slot `parity` — the launch writes
@@ -528,7 +573,8 @@ __global__ void scaler_reset_step_kernel(ScalerState st) {
 // carries the state forward (scale, growth tracker, skip count, the canonical step count): none of it is read by the other blocks.
 __global__ void adamw_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                    size_t n, float lr, float b1, float b2, float eps, float wd, ScalerState st,
-                                   const int* __restrict__ nsel, int parity, int dynamic, float growth, float backoff, int interval) {
+                                   const int* __restrict__ nsel, int parity, int dynamic, float growth, float backoff, int interval,
+                                   const LoraImages im) {
     __shared__ float s_bc[2];
     const bool none = nsel && *nsel == 0;            // deyo.py:183: neither step nor update when nothing was selected
     const bool inf = st.i[SC_FOUND_INF] != 0;
@@ -557,28 +603,28 @@ __global__ void adamw_fused_kernel(float* __restrict__ p, const float* __restric
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];
-    float gi = g[i];
-    float pi = p[i] * (1.0f - lr * wd);
-    float mi = b1 * m[i] + (1.0f - b1) * gi;
-    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    float mi = m[i], vi = v[i];
+    const float pn = adamw_elem(p[i], g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+    p[i] = pn;
     m[i] = mi;
     v[i] = vi;
+    if (im.layers > 0) write_lora_images(im, i, pn);      // (a skipped step leaves parameters AND images as they are)
 }
 
 // LoRA_AB.reset() + optimizer.load_state_dict(empty) (clip/custom_clip.py:202-215, ttl.py:344) + the scaler's per-image step
 // counters in one launch; the loss scale PERSISTS (the reference's only cross-image state, Q14)
 __global__ void episode_reset_kernel(float* __restrict__ p, const float* __restrict__ snap, float* __restrict__ m,
-                                     float* __restrict__ v, size_t n, ScalerState st) {
+                                     float* __restrict__ v, size_t n, ScalerState st, const LoraImages im) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st.i[SC_STEP] = 0; st.i[SC_DO_STEP] = 0; st.i[SC_FOUND_INF] = 0; st.i[SC_STEP_A] = 0; st.i[SC_STEP_B] = 0;
     }
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    p[i] = snap[i];
+    const float x = snap[i];
+    p[i] = x;
     m[i] = 0.f;
     v[i] = 0.f;
+    if (im.layers > 0) write_lora_images(im, i, x);
 }
 
 // accuracy(output, target, topk=(1, 5)) of utils/tools.py:88-102 as integer hit counts for ONE prediction row, accumulated on
@@ -719,14 +765,17 @@ hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, si
 
 hipError_t launch_adamw_fused(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
                               ScalerState st, const int* n_selected, int parity, int dynamic, float growth, float backoff, int interval,
-                              hipStream_t s) {
+                              hipStream_t s, const LoraImages* img) {
+    LoraImages none = {};
     hipLaunchKernelGGL(adamw_fused_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, st,
-                       n_selected, parity & 1, dynamic, growth, backoff, interval);
+                       n_selected, parity & 1, dynamic, growth, backoff, interval, img ? *img : none);
     return hipGetLastError();
 }
 
-hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t s) {
-    hipLaunchKernelGGL(episode_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, snap, m, v, n, st);
+hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t s,
+                                const LoraImages* img) {
+    LoraImages none = {};
+    hipLaunchKernelGGL(episode_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, snap, m, v, n, st, img ? *img : none);
     return hipGetLastError();
 }
 

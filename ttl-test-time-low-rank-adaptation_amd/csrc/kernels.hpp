@@ -202,10 +202,22 @@ hipError_t launch_scaler_reset_step(ScalerState st, hipStream_t s);
 // The fused episode's forms (one launch each): launch_scaler_pre_step + launch_adamw_dev with the step count read from slot
 // `parity` & 1 and written to the other slot (update u of an episode passes u; launch_episode_reset zeroes both slots);
 // launch_lora_reset (m, v required) + launch_scaler_reset_step.
+// `img` (optional, img.layers > 0): the operand-dtype images derived from the LoRA parameters (launch_lora_refresh's outputs) are
+// written by the same launch, element by element as the parameter is: the forward that follows needs no refresh launches.
+constexpr int LORA_IMG_MAX_LAYERS = 24;
+struct LoraLayerImages { op_t *wext, *wtext, *acat, *btcat, *woext, *wotext, *acat_o, *btcat_o; };
+struct LoraImages {
+    int layers;            // trained layers with adapters (0: no image writes)
+    int ntg;               // adapters per layer, in the bound buffer's order (q, k, v, out among the enabled ones)
+    int D, r, ldw, ldwt, ldwo;
+    int proj[4];           // per adapter slot: 0 q / 1 k / 2 v (slot k of the q/k/v images) or 3 = out_proj
+    LoraLayerImages L[LORA_IMG_MAX_LAYERS];
+};
 hipError_t launch_adamw_fused(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
                               ScalerState st, const int* n_selected, int parity, int dynamic, float growth, float backoff, int interval,
-                              hipStream_t s);
-hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t s);
+                              hipStream_t s, const LoraImages* img = nullptr);
+hipError_t launch_episode_reset(float* p, const float* snap, float* m, float* v, size_t n, ScalerState st, hipStream_t s,
+                                const LoraImages* img = nullptr);
 // utils/tools.py:88-102 accuracy(output, target, (1, 5)) for one prediction row [1,K]: hits[0..2] += {top-1 hit, top-5 hit, 1}
 hipError_t launch_topk_hits(const float* logits, int K, const long long* target, long long* hits, hipStream_t s);
 hipError_t launch_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, hipStream_t s);

@@ -383,6 +383,8 @@ class EpisodePipeline:
         # one copy of the frozen weights per GPU (the reference's single `model`, ttl.py:178-179): slots after the first read
         # slot 0's images (ttl_ctx_create_shared).  TTL_SHARE_WEIGHTS=0: a private copy per slot (A/B, tools/ab_env.py).
         share = os.environ.get("TTL_SHARE_WEIGHTS", "1") != "0"
+        # TTL_STREAM_PRIOS="-1,0,0" (experiments): a HIP stream priority per slot (lower = more urgent); default: all equal
+        prios = [int(v) for v in os.environ.get("TTL_STREAM_PRIOS", "").split(",") if v.strip()]
         for _ in range(max(1, int(n_streams))):
             if engine_factory is not None:
                 eng = engine_factory()
@@ -395,7 +397,8 @@ class EpisodePipeline:
             flat = torch.cat([torch.as_tensor(lora_init[k]).reshape(-1).float() for k in lora_names]).to(dev).contiguous()
             eng.bind_lora(flat)
             self.slots.append(dict(eng=eng, flat=flat, snap=flat.clone(), m=torch.zeros_like(flat), v=torch.zeros_like(flat),
-                                   stream=torch.cuda.Stream(device=dev),
+                                   stream=torch.cuda.Stream(device=dev, priority=prios[len(self.slots) % len(prios)]) if prios
+                                   else torch.cuda.Stream(device=dev),
                                    acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
         self._next = 0
         # use_graph: every slot replays its episode as ONE hipGraphLaunch (captured on first use per argument set)
