@@ -2,6 +2,8 @@
 // LayerNorm forward/backward (wave per row, fp32 statistics).
 // Reference ops replaced: nn.LayerNorm (HF modeling_clip.py:605,358-360,607) and its autograd;
 // Conv2d input unfolding (:202-218).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace {
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < LN_MAXC; ++i) {
             int c = lane + 64 * i;
+#if defined(TTL_LN_VARIANT) && TTL_LN_VARIANT == 3
+            if (c < nch) { const float* pp = xr + 4 * c; v[r][i] = make_float4(__builtin_nontemporal_load(pp), __builtin_nontemporal_load(pp + 1), __builtin_nontemporal_load(pp + 2), __builtin_nontemporal_load(pp + 3)); }
+#else
             if (c < nch) v[r][i] = *(const float4*)(xr + 4 * c);
+#endif
             else v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -150,6 +156,66 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
     }
 }
+
+// TTL_LN_VARIANT (tools/ew_macro_ab.sh): 0 = one row per wave, one wave per row (rounds 1-3); 2 = persistent waves (TTL_LN_PBLK
+// blocks of 4 per CU) walking rows with the NEXT row's loads in flight while the current row is reduced and written (round 4, used
+// for the big launches); 3 = variant 0 with non-temporal loads of x.  In situ, layernorm / elementwise class per episode:
+// 0.545 ms (0), 0.516 / 0.513 / 0.525 (2 with 4 / 8 / 2 blocks per CU), 0.562 (3): profiles/r04_ln_variants.txt.
+#ifndef TTL_LN_VARIANT
+#define TTL_LN_VARIANT 2
+#endif
+#if TTL_LN_VARIANT == 2
+__global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, op_t* __restrict__ y16, int ld16,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nch = D >> 2;
+    float4 g[LN_MAXC], b[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = min(lane + 64 * i, nch - 1);
+        g[i] = *(const float4*)(gamma + 4 * c); b[i] = *(const float4*)(beta + 4 * c);
+    }
+    float4 cur[LN_MAXC], nxt[LN_MAXC];
+    int row = w;
+    if (row >= rows) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) cur[i] = *(const float4*)(x + (size_t)row * D + 4 * min(lane + 64 * i, nch - 1));
+    for (; row < rows; row += nw) {
+        const int rn = min(row + nw, rows - 1);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) nxt[i] = *(const float4*)(x + (size_t)rn * D + 4 * min(lane + 64 * i, nch - 1));
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            if (lane + 64 * i >= nch) cur[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (cur[i].x + cur[i].y) + (cur[i].z + cur[i].w);
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i)
+            if (lane + 64 * i < nch) {
+                const float a0 = cur[i].x - mu, a1 = cur[i].y - mu, a2 = cur[i].z - mu, a3 = cur[i].w - mu;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float o0 = (cur[i].x - mu) * rs * g[i].x + b[i].x, o1 = (cur[i].y - mu) * rs * g[i].y + b[i].y;
+                const float o2 = (cur[i].z - mu) * rs * g[i].z + b[i].z, o3 = (cur[i].w - mu) * rs * g[i].w + b[i].w;
+                *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) cur[i] = nxt[i];
+    }
+}
+#endif
 
 // dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * gamma,  xh = (x - mean) * rstd
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -315,6 +381,14 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
 #ifdef TTL_DIAG_SKIP       // timing-only ablation of the episode (tools/class_cost_ab.sh): bit 0 = no big LayerNorm forward launches
     { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && rows >= 4096 && diag_skip_now(cnt, 1320)) return hipSuccess; }
+#endif
+#if TTL_LN_VARIANT == 2
+    if (rows >= 4096 && !y_f32 && y_bf16 && !rowmap && row_stride == D) {
+        const int cus = device_cu_count();
+        static const int pblk = [] { const char* v = getenv("TTL_LN_PBLK"); return v ? atoi(v) : 8; }();
+        hipLaunchKernelGGL(ln_fwd_persist_kernel, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
+        return hipGetLastError();
+    }
 #endif
     // several rows per wave only where there are rows to spare (big launches); small ones stay one row per wave
     if (TTL_LN_RPW > 1 && rows >= 4096)

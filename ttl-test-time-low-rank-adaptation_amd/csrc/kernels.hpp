@@ -242,7 +242,11 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
 // scaler_f / scaler_i (ScalerState arrays, may be null): the gradients are divided by the loss scale scaler_f[0] and any
 // non-finite value sets scaler_i[0] (found_inf).
 constexpr int WGRAD_MAX = 8;
-struct WgradProd { const op_t* S; long long lds; const op_t* G; long long ldg; float* out; int transpose; };
+struct WgradProd {
+    const op_t* S; long long lds; const op_t* G; long long ldg; float* out; int transpose;
+    // filled in by launch_lora_wgrad: second output (rows r.. of a merged product), result rows, offset of the partials
+    float* out2; int rows; size_t poff;
+};
 struct WgradList { WgradProd p[WGRAD_MAX]; int n; };
 hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* partial, hipStream_t s,
                              const float* scaler_f = nullptr, int* scaler_i = nullptr);

@@ -100,12 +100,12 @@ constexpr int WG_BN = 128;   // result columns per block
 __device__ __forceinline__ int wg_u(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <int R>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, int D, float* __restrict__ partial, int nch) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, int D, float* __restrict__ partial, int nch, int prod0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sG = smem;                       // [256][128] bf16, 256-B rows, 16-B chunk c at c ^ (u(row) << 1)
     char* sS = smem + WG_CH * WG_BN * 2;   // [256][R] bf16, plain
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x, cb = blockIdx.y, prod = blockIdx.z;
+    const int ch = blockIdx.x, cb = blockIdx.y, prod = prod0 + blockIdx.z;
     const int m0 = ch * WG_CH, n0 = cb * WG_BN;
     // operands of this product: result [R][D] = S^T · G over the M rows
     const op_t* S = L.p[prod].S; const long long lds_ = L.p[prod].lds;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(sf[a], gf[b], acc[a][b], 0, 0, 0);
     }
-    float* po = partial + ((size_t)prod * nch + ch) * R * D;
+    float* po = partial + L.p[prod].poff + (size_t)ch * R * D;
 #pragma unroll
     for (int a = 0; a < R / 16; ++a)
 #pragma unroll
@@ -171,24 +171,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __shared__ float part[4][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     const int prod = blockIdx.y;
+    const int rows = L.p[prod].rows;        // r, or 2r for two products that share their G operand (rows r.. belong to out2)
     float a0 = 0.f, a1 = 0.f;
-    if (i < r * D) {
-        const float* p = partial + (size_t)prod * nch * r * D + i;
+    if (i < rows * D) {
+        const float* p = partial + L.p[prod].poff + i;
+        const size_t cs = (size_t)rows * D;
         int c = slice;
-        for (; c + 4 < nch; c += 8) { a0 += p[(size_t)c * r * D]; a1 += p[(size_t)(c + 4) * r * D]; }
-        for (; c < nch; c += 4) a0 += p[(size_t)c * r * D];
+        for (; c + 4 < nch; c += 8) { a0 += p[(size_t)c * cs]; a1 += p[(size_t)(c + 4) * cs]; }
+        for (; c < nch; c += 4) a0 += p[(size_t)c * cs];
     }
     part[slice][threadIdx.x & 63] = a0 + a1;
     __syncthreads();
-    if (slice != 0 || i >= r * D) return;
+    if (slice != 0 || i >= rows * D) return;
     float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     // scaler.unscale_: undo the backward's loss scale; any inf/nan makes the optimizer skip the WHOLE step (deyo.py:186-188)
     if (scaler_f) s *= scaler_f[1];
     if (scaler_i && !isfinite(s)) atomicOr(scaler_i, 1);
-    int j = i / D, d = i - j * D;
+    int j = i / D;
+    const int d = i - j * D;
     float* out = L.p[prod].out;
+    if (j >= r) { j -= r; out = L.p[prod].out2; }
     if (L.p[prod].transpose) out[(size_t)d * r + j] = s;   // dB [D][r]
-    else out[i] = s;                                        // dA [r][D]
+    else out[(size_t)j * D + d] = s;                        // dA [r][D]
 }
 
 }  // namespace
@@ -239,24 +243,60 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
 
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
 
-hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* partial, hipStream_t s, const float* scaler_f, int* scaler_i) {
-    if (D % WG_BN || L.n < 1 || L.n > WGRAD_MAX) return hipErrorInvalidValue;
+hipError_t launch_lora_wgrad(const WgradList& L0, int M, int D, int r, float* partial, hipStream_t s, const float* scaler_f, int* scaler_i) {
+    if (D % WG_BN || L0.n < 1 || L0.n > WGRAD_MAX) return hipErrorInvalidValue;
 #ifdef TTL_DIAG_SKIP
     { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && M >= 4096 && diag_skip_now(cnt, 120)) return hipSuccess; }
 #endif
     const int nch = lora_wgrad_chunks(M);
-    dim3 grid(nch, D / WG_BN, L.n);
+    // Two products over the SAME G rows whose S columns lie side by side (dA_q = dU_q^T x1 and dA_v = dU_v^T x1: G = x1, the dU
+    // columns adjacent in the K-extension of dqkv) can run as ONE product with 2r result rows, so that G — 19.4 MB at 64 views — is
+    // read once (TTL_WGRAD_MERGE=1; rank 16 only).  Measured in situ (round 4, tools/_diag/r04m.sh): lora class 0.218 -> 0.225 ms per
+    // episode, episode time unchanged — the 32-row tile halves the resident blocks per CU and the kernel is bound by its
+    // load -> barrier -> multiply round trips, not by the bytes: OFF by default.  Merged products first, so each kernel
+    // instantiation covers a contiguous range of the list.
+    WgradList L = {};
+    bool used[WGRAD_MAX] = {};
+    static const int merge = [] { const char* v = getenv("TTL_WGRAD_MERGE"); return v ? atoi(v) : 0; }();
+    int nm = 0;
+    if (r == 16 && merge)
+        for (int i = 0; i < L0.n; ++i) {
+            if (used[i]) continue;
+            for (int j = i + 1; j < L0.n; ++j) {
+                if (used[j] || L0.p[j].G != L0.p[i].G || L0.p[j].ldg != L0.p[i].ldg || L0.p[j].lds != L0.p[i].lds ||
+                    L0.p[j].transpose != L0.p[i].transpose)
+                    continue;
+                const bool ij = L0.p[j].S == L0.p[i].S + r, ji = L0.p[i].S == L0.p[j].S + r;
+                if (!ij && !ji) continue;
+                WgradProd m = ij ? L0.p[i] : L0.p[j];
+                m.out2 = ij ? L0.p[j].out : L0.p[i].out;
+                m.rows = 2 * r;
+                L.p[L.n++] = m;
+                used[i] = used[j] = true;
+                ++nm;
+                break;
+            }
+        }
+    for (int i = 0; i < L0.n; ++i)
+        if (!used[i]) { L.p[L.n] = L0.p[i]; L.p[L.n].out2 = nullptr; L.p[L.n].rows = r; ++L.n; }
+    size_t off = 0;
+    for (int i = 0; i < L.n; ++i) { L.p[i].poff = off; off += (size_t)nch * L.p[i].rows * D; }
+    auto launch = [&](auto kern, int R, int prod0, int count) -> hipError_t {
+        if (count <= 0) return hipSuccess;
+        const int SMEM = WG_CH * WG_BN * 2 + WG_CH * R * 2;
+        hipLaunchKernelGGL(kern, dim3(nch, D / WG_BN, count), dim3(256), SMEM, s, L, M, D, partial, nch, prod0);
+        return hipGetLastError();
+    };
+    static std::atomic<uint64_t> done16{0}, done32{0};
+    hipError_t e = ensure_smem((const void*)wgrad_kernel<16>, WG_CH * WG_BN * 2 + WG_CH * 16 * 2, done16);
+    if (e == hipSuccess) e = ensure_smem((const void*)wgrad_kernel<32>, WG_CH * WG_BN * 2 + WG_CH * 32 * 2, done32);
+    if (e != hipSuccess) return e;
     if (r == 16) {
-        constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 16 * 2;
-        static std::atomic<uint64_t> done{0};
-        if (hipError_t e = ensure_smem((const void*)wgrad_kernel<16>, SMEM, done); e != hipSuccess) return e;
-        hipLaunchKernelGGL((wgrad_kernel<16>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
+        if ((e = launch(wgrad_kernel<32>, 32, 0, nm)) != hipSuccess) return e;
+        if ((e = launch(wgrad_kernel<16>, 16, nm, L.n - nm)) != hipSuccess) return e;
     } else if (r == 32) {
-        constexpr int SMEM = WG_CH * WG_BN * 2 + WG_CH * 32 * 2;
-        static std::atomic<uint64_t> done{0};
-        if (hipError_t e = ensure_smem((const void*)wgrad_kernel<32>, SMEM, done); e != hipSuccess) return e;
-        hipLaunchKernelGGL((wgrad_kernel<32>), grid, dim3(256), SMEM, s, L, M, D, partial, nch);
+        if ((e = launch(wgrad_kernel<32>, 32, 0, L.n)) != hipSuccess) return e;
     } else return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((r * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((2 * r * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);
     return hipGetLastError();
 }
