@@ -25,9 +25,14 @@ def short(d):
     return {"value": d["value"], "value_min": d.get("value_min"), "value_max": d.get("value_max"), "unit": d["unit"],
             "ms_per_step": d["ms_per_step"], "host_enqueue_ms_per_image": d.get("host_enqueue_ms_per_image"),
             "hip_graph": d["config"].get("hip_graph"), "config": d["config"]["workload"],
+            "dtype": d.get("dtype"),
             "gemm_tflops_alone": r["achieved"], "gemm_frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
-            "whole_path_frac_of_bf16_peak": d.get("whole_path_frac_of_bf16_peak"),
-            "whole_path_frac_executed": d.get("whole_path_frac_executed")}
+            # the roofline figure of the whole path: FLOPs this build EXECUTES (measured sum 2MNK of every GEMM launch + the attention /
+            # LoRA / head FLOPs) x images/s / peak.  Multi-update configurations resume at the first trained layer for updates 2..n
+            # (identical results), so the reference's own FLOP count — which repeats layers 0-8 per update — is work the hardware never
+            # does: it is given for orientation only, under a name that says so.
+            "whole_path_frac_executed": d.get("whole_path_frac_executed"),
+            "reference_flops_x_rate_over_peak__counts_work_this_build_skips": d.get("whole_path_frac_of_bf16_peak")}
 
 
 def main(src, tag):
@@ -45,7 +50,7 @@ def main(src, tag):
         shutil.copy(f"{src}/prof1_gemm_shapes.txt", f"{out}/{tag}_gemm_shapes_serialized.txt")
     other = {}
     for key, f in (("streams1", "bench_streams1.json"), ("adapters_q_k_v_out", "bench_qkvo.json"), ("plain_enqueues_no_graph", "bench_graph0.json"),
-                   ("fp16_operands_as_the_benched_build", "bench_fp16.json"), ("k1000", "bench_k1000.json"), ("vit_l14", "bench_l14.json"),
+                   ("k1000", "bench_k1000.json"), ("vit_l14", "bench_l14.json"),
                    ("r32_128v_4updates", "bench_r32_128v_4up.json"), ("r32_128v_16updates", "bench_r32_128v_16up.json"),
                    ("8views_k10_hip_graph", "bench_8v_graph.json")):
         d = last_json(f"{src}/{f}")
@@ -65,7 +70,9 @@ def main(src, tag):
             blocks = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) if "Grid_Size_X" in r else 0
             dur.setdefault((n.split("<")[0], blocks), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         M, D = 12608, 768
+        cus8 = 256 * 8
         spec = {"ln_fwd_kernel": (3152, M * D * 4 + M * D * 2, "read fp32 [M,D] + write operand [M,D]"),
+                "ln_fwd_persist_kernel": (cus8, M * D * 4 + M * D * 2, "read fp32 [M,D] + write operand [M,D] (persistent waves, next row prefetched: round 4)"),
                 "ln_bwd_kernel": (3152, M * D * (4 + 4 + 4 + 4 + 2), "read dy, x fp32 + residual gradient fp32, write fp32 + operand [M,D]"),
                 "im2col_kernel": (4704, 64 * 3 * 224 * 224 * 4 + 12544 * 768 * 2, "read 64x3x224x224 fp32, write operand patches [12544,768]")}
         k = {}

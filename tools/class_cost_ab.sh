@@ -14,7 +14,7 @@ mkdir -p gpurun_out
 # plain launches (a captured graph would keep the launches that were issued at capture time); every variant issues its class
 # normally through the warm-up and the first part of the first timed block, so the buffers downstream hold realistic data; the
 # median of the three blocks is a block in which the class is not issued
-Q="--no-cpu-baseline --no-parity --precision bf16 --steps 150 --repeats 3 --graph 0"
+Q="--no-cpu-baseline --no-parity --precision bf16 --steps 150 --repeats 3 --graph 0 --variant-lib"
 run() { TTL_HIP_LIB_BF16=$2 python bench.py $Q 2>/dev/null | python -c "
 import sys, json
 d = [json.loads(l) for l in sys.stdin if l.startswith('{')][-1]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC evidence of a round (separate passes: the MI355X guide's HBM/rocprofv3 section; never combined with trace domains):
 #   bash tools/collect_pmc.sh r02      -> gpurun_out/r02/pmc_*/ ; summary + traffic json under gpurun_out/r02/
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$R; mkdir -p $O
 # every pass under its own timeout: a counter set the hardware cannot collect makes rocprofv3 abort and then hang
 pass() { name=$1; shift; timeout 200 rocprofv3 --pmc "$@" -d $O/pmc_$name -o $name --output-format csv -- python3 tools/quick_bench.py > $O/pmc_$name.log 2>&1; echo "pass $name rc=$?"; }

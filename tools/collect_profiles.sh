@@ -5,7 +5,7 @@
 # kernel-stats file is collected (plain enqueues, one stream); the 3-episodes-in-flight regime exists only in bench.py's own
 # event timing (roofline.episodes_in_flight) and in the end-to-end rate.
 #   bash tools/collect_profiles.sh r03
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R; mkdir -p $O
@@ -15,7 +15,6 @@ Q="--no-cpu-baseline --no-parity --precision bf16"
 rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 $Q > $O/prof1.log 2>&1
 python3 bench.py --lora-targets qkvo $Q > $O/bench_qkvo.json 2>> $O/bench.err
 python3 bench.py --graph 0 $Q > $O/bench_graph0.json 2>> $O/bench.err
-python3 bench.py --precision fp16 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
 python3 bench.py --classes 1000 $Q > $O/bench_k1000.json 2>> $O/bench.err
 python3 bench.py --arch ViT-L/14 --steps 60 $Q > $O/bench_l14.json 2>> $O/bench.err
 python3 bench.py --views 128 --classes 1000 --rank 32 --updates 4 --steps 40 $Q > $O/bench_r32_128v_4up.json 2>> $O/bench.err
