@@ -60,7 +60,18 @@ def main(src, tag):
         if os.path.exists(f"{src}/{f}"):
             other[key] = [l.strip() for l in open(f"{src}/{f}").read().strip().split("\n")
                           if l.strip() and "amdgpu.ids" not in l][-6:]
+    sweep = {}
+    for n in (2, 3, 4):          # stream-count sweep of the bf16 build (collected after the PMC passes, same lease)
+        d = last_json(f"{src}/bench_streams{n}.json")
+        if d:
+            sweep[f"streams{n}"] = {k: d[k] for k in ("value", "value_min", "value_max", "ms_per_step", "host_enqueue_ms_per_image", "repeats", "steps")}
+            sweep[f"streams{n}"]["hip_graph"] = d["protocol"]["hip_graph"]
+    if sweep:
+        other["streams_sweep_bf16"] = sweep
     json.dump(other, open(f"{out}/{tag}_other_configs.json", "w"), indent=1)
+    for f in ("pmc_summary.txt", "pmc_memory_path.txt", "gemm_traffic.json", "class_cost_in_flight.txt", "parity_per_fixture.txt"):
+        if os.path.exists(f"{src}/{f}"):
+            shutil.copy(f"{src}/{f}", f"{out}/{tag}_{f}")
     # HBM-bound kernels: per-launch durations from the 1-stream kernel trace
     trace = [os.path.join(dp, f) for dp, _, fs in os.walk(f"{src}/prof1") for f in fs if f.endswith("kernel_trace.csv")]
     if trace:
