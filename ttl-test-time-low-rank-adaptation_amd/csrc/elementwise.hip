@@ -165,59 +165,83 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #define TTL_LN_VARIANT 2
 #endif
 #if TTL_LN_VARIANT == 2
-__global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// TTL_LN_HOLD_GB 0: gamma / beta are re-read per row (L1 hits) instead of held in 32 registers, and the kernel is capped at 64 VGPRs —
+// what is left per SIMD beside two big-M GEMM waves (2 x 224 of 512), so that its blocks can run on a CU another episode's GEMM holds
+#ifndef TTL_LN_HOLD_GB
+#define TTL_LN_HOLD_GB 1
+#endif
+#if TTL_LN_HOLD_GB
+#define LN_PERSIST_ATTR
+#else
+#define LN_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(8)))
+#endif
+template <int NC>     // NC float4 chunks per lane: 3 for D <= 768 (ViT-B, exact: no masks), 4 up to D = 1024
+__global__ __launch_bounds__(256) LN_PERSIST_ATTR void ln_fwd_persist_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, op_t* __restrict__ y16, int ld16,
                                                              float* __restrict__ mean, float* __restrict__ rstd, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4, w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nch = D >> 2;
-    float4 g[LN_MAXC], b[LN_MAXC];
+#if TTL_LN_HOLD_GB
+    float4 g[NC], b[NC];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = min(lane + 64 * i, nch - 1);
         g[i] = *(const float4*)(gamma + 4 * c); b[i] = *(const float4*)(beta + 4 * c);
     }
-    float4 cur[LN_MAXC], nxt[LN_MAXC];
+#define LN_G(i) g[i]
+#define LN_B(i) b[i]
+#else
+#define LN_G(i) (*(const float4*)(gp + 4 * c))
+#define LN_B(i) (*(const float4*)(bp + 4 * c))
+#endif
+    float4 cur[NC], nxt[NC];
     int row = w;
     if (row >= rows) return;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) cur[i] = *(const float4*)(x + (size_t)row * D + 4 * min(lane + 64 * i, nch - 1));
+    for (int i = 0; i < NC; ++i) cur[i] = *(const float4*)(x + (size_t)row * D + 4 * min(lane + 64 * i, nch - 1));
     for (; row < rows; row += nw) {
         const int rn = min(row + nw, rows - 1);
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) nxt[i] = *(const float4*)(x + (size_t)rn * D + 4 * min(lane + 64 * i, nch - 1));
+        for (int i = 0; i < NC; ++i) nxt[i] = *(const float4*)(x + (size_t)rn * D + 4 * min(lane + 64 * i, nch - 1));
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             if (lane + 64 * i >= nch) cur[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             s += (cur[i].x + cur[i].y) + (cur[i].z + cur[i].w);
         }
         const float mu = wave_sum(s) / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i)
+        for (int i = 0; i < NC; ++i)
             if (lane + 64 * i < nch) {
                 const float a0 = cur[i].x - mu, a1 = cur[i].y - mu, a2 = cur[i].z - mu, a3 = cur[i].w - mu;
                 q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
         const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
         if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#if !TTL_LN_HOLD_GB
+        const float *gp = gamma, *bp = beta;
+        asm volatile("" : "+s"(gp), "+s"(bp));      // keeps the loop-invariant gamma / beta loads from being hoisted back into 24 registers
+#endif
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-                const float o0 = (cur[i].x - mu) * rs * g[i].x + b[i].x, o1 = (cur[i].y - mu) * rs * g[i].y + b[i].y;
-                const float o2 = (cur[i].z - mu) * rs * g[i].z + b[i].z, o3 = (cur[i].w - mu) * rs * g[i].w + b[i].w;
+                const float4 gg = LN_G(i), bb = LN_B(i);
+                const float o0 = (cur[i].x - mu) * rs * gg.x + bb.x, o1 = (cur[i].y - mu) * rs * gg.y + bb.y;
+                const float o2 = (cur[i].z - mu) * rs * gg.z + bb.z, o3 = (cur[i].w - mu) * rs * gg.w + bb.w;
                 *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
             }
         }
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
     }
 }
 #endif
 
 // dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * gamma,  xh = (x - mean) * rstd
+template <int NC>     // float4 chunks per lane: 3 for D <= 768 (54 VGPRs: fits beside two big-M GEMM waves per SIMD), 4 up to D = 1024 (66)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -239,10 +263,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (t == (pool ? pool[v] : 0)) dres_row = dres + (size_t)v * D;
         } else dres_row = dres + (size_t)row * os;
     }
-    float4 dxh[LN_MAXC], xh[LN_MAXC];
+    float4 dxh[NC], xh[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
             float4 d = *(const float4*)(dy + (size_t)row * D + 4 * c);
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
             float4 r = dres_row ? *(const float4*)(dres_row + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -386,7 +410,8 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
     if (rows >= 4096 && !y_f32 && y_bf16 && !rowmap && row_stride == D) {
         const int cus = device_cu_count();
         static const int pblk = [] { const char* v = getenv("TTL_LN_PBLK"); return v ? atoi(v) : 8; }();
-        hipLaunchKernelGGL(ln_fwd_persist_kernel, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
+        if (D <= 768) hipLaunchKernelGGL(ln_fwd_persist_kernel<3>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
+        else hipLaunchKernelGGL(ln_fwd_persist_kernel<4>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
         return hipGetLastError();
     }
 #endif
@@ -408,7 +433,8 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* me
     { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 2) && rows >= 4096 && diag_skip_now(cnt, 240)) return hipSuccess; }
 #endif
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
+    auto kern = D <= 768 ? ln_bwd_kernel<3> : ln_bwd_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, out_f32,
                        out_bf16, rows, D, x_stride ? x_stride : (long long)D, o_stride ? o_stride : (long long)D,
                        stat_stride, dres_T, pool, ld_bf16 ? ld_bf16 : (o_stride ? o_stride : (long long)D));
     return hipGetLastError();
