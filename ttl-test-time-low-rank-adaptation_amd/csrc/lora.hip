@@ -51,8 +51,14 @@ __global__ void refresh_kernel(LoraPtrs P, int3 slot /* of q, k, v; -1 = none */
 // result columns of one token: one 8-byte store.  The kernel is pure latency (a few hundred waves, each a serial K loop), so
 // ALL of a wave's X fragments are requested up front (KS x 16 B per lane in flight) and the adapter's rows of Wcat are staged
 // once per workgroup in LDS.  rowmap (optional): logical row m lives at physical row rowmap[m] of X and out.
+// TTL_SKINNY_WPB: waves (16-row groups) per workgroup.  64 views are 788 groups: 4 per workgroup leave 59 of the 256 CUs without any
+// (197 workgroups); fewer per workgroup spread the X reads over every CU at the price of staging Wcat more often (from L2).
+#ifndef TTL_SKINNY_WPB
+#define TTL_SKINNY_WPB 4
+#endif
+constexpr int SK_WPB = TTL_SKINNY_WPB;
 template <int NCG, int KS>   // NCG = r / 16 column groups, KS = D / 32 k-steps
-__global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X, long long ldx, int3 xoff,
+__global__ __launch_bounds__(64 * SK_WPB) void skinny_kernel(const op_t* __restrict__ X, long long ldx, int3 xoff,
                                                      const op_t* __restrict__ Wcat, int D, float scale,
                                                      op_t* __restrict__ out, long long ldo, int M, const int* __restrict__ rowmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // W [16*NCG][D] operand type, rows padded by 16 B
@@ -61,11 +67,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const op_t* __restrict__ X,
     const int xo = t == 0 ? xoff.x : t == 1 ? xoff.y : xoff.z;
     const op_t* W = Wcat + (size_t)t * 16 * NCG * D;
     const int rowb = D * 2 + 16;
-    for (int q = tid; q < 16 * NCG * (D / 8); q += 256) {
+    for (int q = tid; q < 16 * NCG * (D / 8); q += 64 * SK_WPB) {
         int r = q / (D / 8), c = q - r * (D / 8);
         *(u32x4*)(smem + r * rowb + c * 16) = *(const u32x4*)(W + (size_t)r * D + c * 8);
     }
-    const int m0 = (blockIdx.x * 4 + (tid >> 6)) * 16;
+    const int m0 = (blockIdx.x * SK_WPB + (tid >> 6)) * 16;
     const int li = lane & 15, lg = lane >> 4;
     const int row = min(m0 + li, M - 1);
     const long long prow = rowmap ? rowmap[row] : row;
@@ -212,7 +218,8 @@ static hipError_t skinny_launch(const op_t* X, long long ldx, int3 xoff, int ntg
     const int smem = 16 * NCG * (D * 2 + 16);
     static std::atomic<uint64_t> done{0};
     if (hipError_t e = ensure_smem((const void*)skinny_kernel<NCG, KS>, smem, done); e != hipSuccess) return e;
-    hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 63) / 64, ntg), dim3(256), smem, s, X, ldx, xoff, W, D, scale, out, ldo, M, rowmap);
+    hipLaunchKernelGGL((skinny_kernel<NCG, KS>), dim3((M + 16 * SK_WPB - 1) / (16 * SK_WPB), ntg), dim3(64 * SK_WPB), smem, s, X, ldx, xoff, W, D, scale,
+                       out, ldo, M, rowmap);
     return hipGetLastError();
 }
 
