@@ -67,6 +67,10 @@ CASES = {
     # reference's init, so that dA == 0 and the K-extension columns are idle) are set to seeded N(0, 0.02^2) values by the
     # harness AFTER the reference's LoRA_reset and BEFORE its test_time_tuning — input state, the reference's code is untouched
     "b16_n8_k10_qkvo": ("ViT-B/16", 8, 10, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "lora_B_std": 0.02}),
+    # the same adapter set on the benched workload (64 views, K = 200): what `bench.py --lora-targets qkvo` runs
+    "b16_n64_k200_qkvo": ("ViT-B/16", 64, 200, {"target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"], "lora_B_std": 0.02}),
+    # BASELINE.json configs[3] at its full view count (ViT-L/14, 64 views, K = 200): ~20 minutes of the reference on CPU
+    "l14_n64_k200": ("ViT-L/14", 64, 200, {}),
     # a multi-update episode with adapters on all four projections and NON-ZERO B from the start: every gradient (k_proj's included,
     # which is fp32 noise while B == 0) is a real signal in every update, so the oracle is pinned tightly through the resumed forward
     # and the multi-step backward of the q/k/v/out path (round-3 advisor; tiny_qkvo_steps2 can only be compared loosely)

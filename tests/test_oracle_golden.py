@@ -1,5 +1,7 @@
 """Pins oracle/ttl_oracle.py (the CPU restatement) against fixtures produced by the
 reference itself (tests/golden/make_golden.py).  Runs on CPU; no GPU, no /root/reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -169,8 +171,12 @@ def test_episode_b16_r32_n16_steps2():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent1", "b16_n64_k200_outliers"])
+@pytest.mark.parametrize("name", ["b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent1", "b16_n64_k200_outliers", "b16_n64_k200_qkvo",
+                                  "l14_n64_k200"])
 def test_episode_b16_n64(name):
+    # ViT-L/14 at 64 views is 170 s of numpy on 8 cores (passes, round 4): opt-in, so that the default CPU suite stays at minutes
+    if name == "l14_n64_k200" and not os.environ.get("TTL_FULL_ORACLE"):
+        pytest.skip("set TTL_FULL_ORACLE=1 to pin the oracle on the 64-view ViT-L/14 fixture too (~3 minutes)")
     _run_case(name, check_taps=False)
 
 

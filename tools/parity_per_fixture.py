@@ -5,7 +5,7 @@ ROOT = os.getcwd(); sys.path[:0] = [ROOT, os.path.join(ROOT, "ttl-test-time-low-
 from helpers import load_case, episode_kwargs, max_rel
 from ttl_amd.engine import TTLEngine
 from ttl_amd.config import trainable_names
-for name in ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "b16_n8_k10_qkvo", "l14_n4_k10",
+for name in ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "b16_n8_k10_qkvo", "b16_n64_k200_qkvo", "l14_n4_k10", "l14_n64_k200",
              "b32_n8_k10", "b16_n8_k10_outliers", "b16_n64_k200_outliers", "b16_n64_k200_outliers_ent1"]:
     g, cfg, W, x, lora0, tf = load_case(name); kw = episode_kwargs(g); names = trainable_names(cfg)
     for prec in ("fp16", "bf16"):
