@@ -57,6 +57,9 @@ CASES = {
     # BASELINE.json configs[4]'s features at a CPU-sized view count: rank 32, --tta_steps 2 (= 4 optimizer updates, Q6), top-rho
     # selection (int(16 * 0.1) = 1 view) on the full ViT-B/16 geometry
     "b16_r32_n16_steps2": ("ViT-B/16", 16, 10, {"rank": 32, "tta_steps": 2, "filter_ent": 1}),
+    # BASELINE.json configs[4] at its full size on one GPU: rank 32, 128 views, --tta_steps 2 (= 4 updates), top-rho selection
+    # (int(128 * 0.1) = 12 views), the 1000 ImageNet-Sketch labels: ~10 minutes and ~25 GB of the reference on CPU
+    "b16_r32_n128_k1000_steps2": ("ViT-B/16", 128, 1000, {"rank": 32, "tta_steps": 2, "filter_ent": 1}),
     # adapters on all four attention projections (BASELINE.json north_star).  The reference hard-codes q_proj + v_proj in its
     # LoraConfig (clip/custom_clip.py:586): these two cases run the UNMODIFIED reference with the harness's peft stand-in told to
     # wrap k_proj / out_proj too (_ref_harness.TARGET_MODULES_OVERRIDE); the reference's LoRA_AB still (re-)initialises q and v

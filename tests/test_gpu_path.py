@@ -225,13 +225,14 @@ def test_vit_b16_against_reference_goldens(name):
     eng.close()
 
 
+@pytest.mark.parametrize("fixture,tag", [("b16_r32_n16_steps2", "r32_steps2"), ("b16_r32_n128_k1000_steps2", "r32_n128")])
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_r32_four_updates_against_the_reference(precision):
-    """BASELINE config 5's features through the reference itself (fixture b16_r32_n16_steps2: rank 32, --tta_steps 2 = 4 optimizer
-    updates, top-rho selection of 1 of 16 views, full ViT-B/16): first-forward logits and the selection exactly as for one
-    update; after four sign-like AdamW updates (Q11) the adapted prediction agrees to the operand precision and nearly every
-    adapter element sits where the reference's does."""
-    g, cfg, W, x, lora0, tf = load_case("b16_r32_n16_steps2")
+def test_r32_four_updates_against_the_reference(precision, fixture, tag):
+    """BASELINE config 5 through the reference itself: rank 32, --tta_steps 2 = 4 optimizer updates, top-rho selection, full ViT-B/16 —
+    at 16 views / K = 10 (1 view selected) and at the configuration's own size, 128 views / K = 1000 (12 selected).  First-forward
+    logits and the selection exactly as for one update; after four sign-like AdamW updates (Q11) the adapted prediction agrees to
+    the operand precision and nearly every adapter element sits where the reference's does."""
+    g, cfg, W, x, lora0, tf = load_case(fixture)
     kw = episode_kwargs(g)
     assert kw["n_updates"] == 4 and cfg.rank == 32
     eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision=precision)
@@ -240,10 +241,17 @@ def test_r32_four_updates_against_the_reference(precision):
                          mode=1 if kw["mode"] == "topk" else 0, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"], want_logits0=True)
     torch.cuda.synchronize()
     tol = 8e-3 if precision == "bf16" else 1e-3
-    bound(f"r32_steps2/{precision}/logits0", max_rel(l0.cpu().numpy(), g["logits0"]), tol)
+    z0 = l0.cpu().numpy()
+    bound(f"{tag}/{precision}/logits0", max_rel(z0, g["logits0"]), tol)
+    # the first update's selection (the fixture's idx) from this build's own first-forward logits ...
+    idx0 = O.select_views(O.softmax_entropy(z0), kw["mode"], x.shape[0], kw["rho"])
+    assert np.array_equal(np.sort(idx0), np.sort(np.asarray(g["idx"]).reshape(-1)))
+    # ... and the list the HIP episode used in its LAST update against the reference's last update (the views move in and out of
+    # the top-rho set while the adapters change: 12 of 128 at full size): its selection from its own last-update logits
     hip_idx, _ = eng.last_selection(x.shape[0])
-    assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1)))
-    bound(f"r32_steps2/{precision}/logits1", max_rel(l1.cpu().numpy(), g["logits1"]), 3 * tol)
+    ref_last = O.select_views(O.softmax_entropy(g["logits_last"]), kw["mode"], x.shape[0], kw["rho"])
+    assert np.array_equal(np.sort(hip_idx), np.sort(ref_last)), (np.sort(hip_idx), np.sort(ref_last))
+    bound(f"{tag}/{precision}/logits1", max_rel(l1.cpu().numpy(), g["logits1"]), 3 * tol)
     assert np.array_equal(np.argsort(-l1.cpu().numpy(), 1)[:, :1], g["top5"][:, :1])
     lora1 = split(flat, lora0, names)
     lr = kw["lr"]
@@ -251,7 +259,7 @@ def test_r32_four_updates_against_the_reference(precision):
         err = np.abs(lora1[k].astype(np.float64) - g["lora1/" + k])
         assert err.max() <= 2 * lr * 4 + 1e-6, (k, float(err.max()))
         if np.abs(g["grad/" + k]).max() > 0:
-            bound(f"r32_steps2/{precision}/frac_beyond_0.1lr", (err > 0.1 * lr).mean(), 0.05 if precision == "bf16" else 0.02)
+            bound(f"{tag}/{precision}/frac_beyond_0.1lr", (err > 0.1 * lr).mean(), 0.05 if precision == "bf16" else 0.02)
     eng.close()
 
 
