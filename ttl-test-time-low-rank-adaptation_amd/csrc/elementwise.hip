@@ -350,9 +350,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (resid) acc = *(const float4*)(resid + (size_t)pm * ldr + n);
     if (bias) { float4 b = *(const float4*)(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
-    for (int s = 0; s < splits; ++s) {
-        float4 p = *(const float4*)(part + (size_t)s * M * N + i);
-        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    // the slices are requested together (splits <= 8) and added in index order; one load per loop iteration made hipcc wait
+    // vmcnt(0) eight times in a row
+    float4 p[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) p[s] = *(const float4*)(part + (size_t)min(s, splits - 1) * M * N + i);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (s < splits) { acc.x += p[s].x; acc.y += p[s].y; acc.z += p[s].z; acc.w += p[s].w; }
+    for (int s = 8; s < splits; ++s) {
+        float4 q = *(const float4*)(part + (size_t)s * M * N + i);
+        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
     }
     *(float4*)(out + (size_t)pm * ldc + n) = acc;
 }

@@ -67,18 +67,39 @@ __global__ __launch_bounds__(64 * SK_WPB) void skinny_kernel(const op_t* __restr
     const int xo = t == 0 ? xoff.x : t == 1 ? xoff.y : xoff.z;
     const op_t* W = Wcat + (size_t)t * 16 * NCG * D;
     const int rowb = D * 2 + 16;
-    for (int q = tid; q < 16 * NCG * (D / 8); q += 64 * SK_WPB) {
-        int r = q / (D / 8), c = q - r * (D / 8);
-        *(u32x4*)(smem + r * rowb + c * 16) = *(const u32x4*)(W + (size_t)r * D + c * 8);
-    }
     const int m0 = (blockIdx.x * SK_WPB + (tid >> 6)) * 16;
     const int li = lane & 15, lg = lane >> 4;
     const int row = min(m0 + li, M - 1);
     const long long prow = rowmap ? rowmap[row] : row;
     const op_t* x = X + prow * ldx + xo + 8 * lg;
+    // the wave's X fragments are requested FIRST (KS x 16 B per lane), the adapter rows behind them in batches of unrolled loads:
+    // a `load; store to LDS` loop makes hipcc wait vmcnt(0) in every iteration — 12 serial L2 round trips, which WAS this kernel's
+    // duration (9.6 us at 64 views for 19 MB of X) while the X loads had not even been issued
     opx8 f[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) f[k] = *(const opx8*)(x + 32 * k);
+    {
+        constexpr int CPR = 4 * KS;                                  // 16-B chunks per row of Wcat (D = 32 KS)
+        constexpr int TOT = 16 * NCG * CPR, NT = 64 * SK_WPB;
+        constexpr int PER = (TOT + NT - 1) / NT;                     // chunks per thread
+        constexpr int BATCH = PER < 12 ? PER : 12;
+#pragma unroll
+        for (int b0 = 0; b0 < PER; b0 += BATCH) {
+            u32x4 v[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int q = min(tid + (b0 + j) * NT, TOT - 1);     // (clamped: the guard sits on the store, the load stays branch-free)
+                const int r = q / CPR, c = q - r * CPR;
+                v[j] = *(const u32x4*)(W + (size_t)r * D + c * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int q = tid + (b0 + j) * NT;
+                const int r = q / CPR, c = q - r * CPR;
+                if (b0 + j < PER && q < TOT) *(u32x4*)(smem + r * rowb + c * 16) = v[j];
+            }
+        }
+    }
     __syncthreads();
     f32x4 acc[NCG];
 #pragma unroll
@@ -117,17 +138,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
     const op_t* S = L.p[prod].S; const long long lds_ = L.p[prod].lds;
     const op_t* G = L.p[prod].G; const long long ldg = L.p[prod].ldg;
     // stage G tile: 256 rows x 16 chunks of 16 B
-    for (int q = tid; q < WG_CH * 16; q += 256) {
-        int r = q >> 4, c = q & 15;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (m0 + r < M) v = *(const u32x4*)(G + (long long)(m0 + r) * ldg + n0 + c * 8);
-        *(u32x4*)(sG + r * 256 + ((c ^ (wg_u(r) << 1)) << 4)) = v;
-    }
-    for (int q = tid; q < WG_CH * (R / 8); q += 256) {
-        int r = q / (R / 8), c = q - r * (R / 8);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (m0 + r < M) v = *(const u32x4*)(S + (long long)(m0 + r) * lds_ + c * 8);
-        *(u32x4*)(sS + r * (R * 2) + (c << 4)) = v;
+    // all of a thread's 16 + R/8 tile chunks are requested before the first one is written to LDS (rows beyond M: clamped address,
+    // zero selected afterwards): the `load; store` loop this replaces waited vmcnt(0) per iteration — 16 serial HBM round trips,
+    // ~24 of the launch's 29 us at 64 views
+    {
+        u32x4 gv[16], sv[R / 8];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = tid + 256 * j, r = q >> 4, c = q & 15;
+            gv[j] = *(const u32x4*)(G + (long long)min(m0 + r, M - 1) * ldg + n0 + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j) {
+            const int q = tid + 256 * j, r = q / (R / 8), c = q - r * (R / 8);
+            sv[j] = *(const u32x4*)(S + (long long)min(m0 + r, M - 1) * lds_ + c * 8);
+        }
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = tid + 256 * j, r = q >> 4, c = q & 15;
+            *(u32x4*)(sG + r * 256 + ((c ^ (wg_u(r) << 1)) << 4)) = (m0 + r < M) ? gv[j] : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j) {
+            const int q = tid + 256 * j, r = q / (R / 8), c = q - r * (R / 8);
+            *(u32x4*)(sS + r * (R * 2) + (c << 4)) = (m0 + r < M) ? sv[j] : zero;
+        }
     }
     __syncthreads();
     // wave w owns result columns n0 + 32w .. +31 (two 16-col groups), all R rows
@@ -183,6 +219,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const float* p = partial + L.p[prod].poff + i;
         const size_t cs = (size_t)rows * D;
         int c = slice;
+        // (four iterations of loads in flight at a time; the additions keep their order: a0 takes chunks c, c + 8, ..., a1 c + 4, c + 12, ...)
+        for (; c + 28 < nch; c += 32) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(size_t)(c + 4 * j) * cs];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) { a0 += t[j]; a1 += t[j + 1]; }
+        }
         for (; c + 4 < nch; c += 8) { a0 += p[(size_t)c * cs]; a1 += p[(size_t)(c + 4) * cs]; }
         for (; c < nch; c += 4) a0 += p[(size_t)c * cs];
     }
