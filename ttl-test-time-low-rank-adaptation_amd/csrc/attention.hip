@@ -863,6 +863,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const op_t* __res
 // Last encoder layer of the image tower: only its CLS row reaches the head, so only query 0 of every (view, head)
 // is needed: o_0 = softmax(q_0 K^T / 8) V.  Same rounding points as the dense kernel (P rounded to the operand type
 // before the PV product, row sum taken before rounding); writes row 0 of `out` and lse[.., 0] in place.
+// NIT > 0: 32 * NIT >= T, and the thread's K / V chunks of ALL passes are requested up front (2 NIT x 16 B in flight per lane): with one
+// load per loop iteration hipcc waits vmcnt(0) in every iteration, and the kernel was 14 serial round trips long (9.9 us at 64
+// views for 39 MB).  NIT == 0: any T, loads inside the loops.
+template <int NIT>
 __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restrict__ qkv, const QkvLayout L, op_t* __restrict__ out, int ldo,
                                                            float* __restrict__ lse, int T, int H, const int* __restrict__ qpos,
                                                            int causal) {
@@ -881,12 +885,24 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
     float qc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qc[e] = sq[8 * c + e];
+    opx8 kpre[NIT > 0 ? NIT : 1], vpre[NIT > 0 ? NIT : 1];
+    if constexpr (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int jr = min(32 * it + grp, Tk - 1);
+            kpre[it] = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
+            vpre[it] = *(const opx8*)(vbase + (size_t)jr * ld + 8 * c);
+        }
+    }
     // pass 1: raw scores -> LDS, running max
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < Tk; j0 += 32) {
+#pragma unroll
+    for (int j0 = 0; j0 < (NIT > 0 ? 32 * NIT : Tk); j0 += 32) {
+        if (NIT > 0 && j0 >= Tk) break;
         const int j = j0 + grp;
         const int jr = j < Tk ? j : Tk - 1;
-        opx8 kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
+        opx8 kf;
+        if constexpr (NIT > 0) kf = kpre[j0 / 32]; else kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(qc[e], (float)kf[e], s);
@@ -902,13 +918,16 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
     float sum = 0.f, o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j0 = 0; j0 < Tk; j0 += 32) {
+#pragma unroll
+    for (int j0 = 0; j0 < (NIT > 0 ? 32 * NIT : Tk); j0 += 32) {
+        if (NIT > 0 && j0 >= Tk) break;
         const int j = j0 + grp;
         if (j < Tk) {
             const float pj = __expf((sp[j] - mx) * SCALE);
             if (c == 0) sum += pj;
             const float pb = op_to_f32(f32_to_op(pj));
-            opx8 vf = *(const opx8*)(vbase + (size_t)j * ld + 8 * c);
+            opx8 vf;
+            if constexpr (NIT > 0) vf = vpre[j0 / 32]; else vf = *(const opx8*)(vbase + (size_t)j * ld + 8 * c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, (float)vf[e], o[e]);
         }
@@ -933,7 +952,7 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const op_t* __restric
 // whole backward of a (view, head) collapses to rank-1 work (SURVEY appendix A with q = q_0):
 //   p_j = exp(q0.k_j/8 - lse0), dp_j = do0.v_j, ds_j = p_j (dp_j - do0.o0),
 //   dq_0 = sum_j ds_j k_j / 8,  dk_j = ds_j q0 / 8,  dv_j = p_j do0;   dq_t = 0 for t > 0.
-template <bool NEED_DK>
+template <bool NEED_DK, int NIT>     // NIT as in attn_fwd_cls_kernel
 __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restrict__ qkv, const QkvLayout L, const op_t* __restrict__ out,
                                                            int ldo, const op_t* __restrict__ dout_cls,
                                                            const float* __restrict__ lse, op_t* __restrict__ dqkv, int ldd,
@@ -963,12 +982,24 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const op_t* __restric
     float qc[8], dc[8], dq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { qc[e] = sq[8 * c + e]; dc[e] = sdo[8 * c + e]; dq[e] = 0.f; }
-    for (int j0 = 0; j0 < T; j0 += 32) {
+    opx8 kpre[NIT > 0 ? NIT : 1], vpre[NIT > 0 ? NIT : 1];
+    if constexpr (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int jr = min(32 * it + grp, T - 1);
+            kpre[it] = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
+            vpre[it] = *(const opx8*)(vbase + (size_t)jr * ld + 8 * c);
+        }
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < (NIT > 0 ? 32 * NIT : T); j0 += 32) {
+        if (NIT > 0 && j0 >= T) break;
         const int j = j0 + grp;
         const bool ok = j < T;
         const int jr = ok ? j : T - 1;
-        opx8 kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c);
-        opx8 vf = *(const opx8*)(vbase + (size_t)jr * ld + 8 * c);
+        opx8 kf, vf;
+        if constexpr (NIT > 0) { kf = kpre[j0 / 32]; vf = vpre[j0 / 32]; }
+        else { kf = *(const opx8*)(kbase + (size_t)jr * ld + 8 * c); vf = *(const opx8*)(vbase + (size_t)jr * ld + 8 * c); }
         float s = 0.f, dp = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s = fmaf(qc[e], (float)kf[e], s); dp = fmaf(dc[e], (float)vf[e], dp); }
@@ -1130,18 +1161,21 @@ hipError_t launch_attention_bwd(const op_t* qkv, QkvLayout ld_qkv, const op_t* o
 hipError_t launch_attention_fwd_cls(const op_t* qkv, QkvLayout ld_qkv, op_t* out, int ld_out, float* lse, int n, int T, int H,
                                     hipStream_t s, const int* qpos, int causal) {
     if (T > 320) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H, qpos, causal);
+    const int nit = (T + 31) / 32;
+#define FWD_CLS(N_) hipLaunchKernelGGL(attn_fwd_cls_kernel<N_>, dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_out, lse, T, H, qpos, causal)
+    if (nit <= 3) FWD_CLS(3); else if (nit <= 7) FWD_CLS(7); else if (nit <= 9) FWD_CLS(9); else FWD_CLS(0);
+#undef FWD_CLS
     return hipGetLastError();
 }
 
 hipError_t launch_attention_bwd_cls(const op_t* qkv, QkvLayout ld_qkv, const op_t* out, int ld_o, const op_t* dout_cls,
                                     const float* lse, op_t* dqkv, int ld_dqkv, int n, int T, int H, int need_dk,
                                     hipStream_t s, const int* qpos, int causal) {
-    if (need_dk)
-        hipLaunchKernelGGL((attn_bwd_cls_kernel<true>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
-                           ld_dqkv, T, H, qpos, causal);
-    else
-        hipLaunchKernelGGL((attn_bwd_cls_kernel<false>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv,
-                           ld_dqkv, T, H, qpos, causal);
+    const int nit = (T + 31) / 32;
+#define BWD_CLS(DK_, N_) hipLaunchKernelGGL((attn_bwd_cls_kernel<DK_, N_>), dim3(n * H), dim3(256), 0, s, qkv, ld_qkv, out, ld_o, dout_cls, lse, dqkv, \
+                                           ld_dqkv, T, H, qpos, causal)
+    if (need_dk) { if (nit <= 3) BWD_CLS(true, 3); else if (nit <= 7) BWD_CLS(true, 7); else if (nit <= 9) BWD_CLS(true, 9); else BWD_CLS(true, 0); }
+    else { if (nit <= 3) BWD_CLS(false, 3); else if (nit <= 7) BWD_CLS(false, 7); else if (nit <= 9) BWD_CLS(false, 9); else BWD_CLS(false, 0); }
+#undef BWD_CLS
     return hipGetLastError();
 }
