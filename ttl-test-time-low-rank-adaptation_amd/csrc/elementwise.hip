@@ -103,6 +103,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int nch = D >> 2;
     float4 v[RPW][LN_MAXC];
     float s[RPW];
+    // gamma / beta travel with the row (clamped index, no branch): loaded behind the reductions they were a second, serial round trip
+    float4 gam[LN_MAXC], bet[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = min(lane + 64 * i, nch - 1);
+        gam[i] = *(const float4*)(gamma + 4 * c); bet[i] = *(const float4*)(beta + 4 * c);
+    }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, rows - 1);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         for (int i = 0; i < LN_MAXC; ++i) {
             int c = lane + 64 * i;
             if (c < nch) {
-                float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+                const float4 g = gam[i], b = bet[i];
                 float o0 = (v[r][i].x - mu) * rs * g.x + b.x, o1 = (v[r][i].y - mu) * rs * g.y + b.y;
                 float o2 = (v[r][i].z - mu) * rs * g.z + b.z, o3 = (v[r][i].w - mu) * rs * g.w + b.w;
                 if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
@@ -263,17 +270,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (t == (pool ? pool[v] : 0)) dres_row = dres + (size_t)v * D;
         } else dres_row = dres + (size_t)row * os;
     }
+    // every load of the row is requested before the first use, with clamped chunk indices and selects instead of branches (a guard
+    // around a load makes hipcc wait vmcnt(0) right behind it: the guarded version of this kernel was seven serial round trips per row)
+    float4 d[NC], xv[NC], g[NC], rr[NC];
+    const float* rsrc = dres_row ? dres_row : dy + (size_t)row * D;     // (no residual gradient: any readable row, zero selected below)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = min(lane + 64 * i, nch - 1);
+        d[i] = *(const float4*)(dy + (size_t)row * D + 4 * c);
+        xv[i] = *(const float4*)(x + (size_t)row * xs + 4 * c);
+        g[i] = *(const float4*)(gamma + 4 * c);
+        rr[i] = *(const float4*)(rsrc + 4 * c);
+    }
     float4 dxh[NC], xh[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
-            float4 d = *(const float4*)(dy + (size_t)row * D + 4 * c);
-            float4 xv = *(const float4*)(x + (size_t)row * xs + 4 * c);
-            float4 g = *(const float4*)(gamma + 4 * c);
-            dxh[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            dxh[i] = make_float4(d[i].x * g[i].x, d[i].y * g[i].y, d[i].z * g[i].z, d[i].w * g[i].w);
+            xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
             s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
             s2 += (dxh[i].x * xh[i].x + dxh[i].y * xh[i].y) + (dxh[i].z * xh[i].z + dxh[i].w * xh[i].w);
         }
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < NC; ++i) {
         int c = lane + 64 * i;
         if (c < nch) {
-            float4 r = dres_row ? *(const float4*)(dres_row + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 r = dres_row ? rr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
