@@ -105,29 +105,10 @@ __global__ __launch_bounds__(256) void views_kernel(const unsigned char* __restr
     const int* tx = table + ((size_t)(v * 2 + 1) * S + oxs) * kstride;
     const int y0 = ty[0], ny = ty[1], x0 = tx[0], nx = tx[1];
     int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-    // The horizontal taps are the same for every source row: read once, and a row's first VT taps are requested together (clamped
-    // index, zero weight beyond nx).  One `load; multiply-add` per loop iteration compiles to a wait per tap — ny * nx serial round
-    // trips per pixel, which is what this kernel's time was (the arithmetic is a few hundred integer operations per pixel).
-    constexpr int VT = 12;        // covers down-scales up to ~2.5x with the bicubic window (views_kstride); wider windows: tail loop
-    int kx[VT];
-#pragma unroll
-    for (int x = 0; x < VT; ++x) { const int k = tx[2 + min(x, max(nx - 1, 0))]; kx[x] = x < nx ? k : 0; }
     for (int y = 0; y < ny; ++y) {
         const unsigned char* row = img + ((size_t)(y0 + y) * W + x0) * 3;
         int h0 = 1 << (PRECISION_BITS - 1), h1 = h0, h2 = h0;
-        unsigned char px[VT][3];
-#pragma unroll
-        for (int x = 0; x < VT; ++x) {
-            const int xc = min(x, max(nx - 1, 0));
-            px[x][0] = row[3 * xc]; px[x][1] = row[3 * xc + 1]; px[x][2] = row[3 * xc + 2];
-        }
-#pragma unroll
-        for (int x = 0; x < VT; ++x) {         // (same order of the integer additions as the tap loop: exact anyway)
-            h0 += (int)px[x][0] * kx[x];
-            h1 += (int)px[x][1] * kx[x];
-            h2 += (int)px[x][2] * kx[x];
-        }
-        for (int x = VT; x < nx; ++x) {
+        for (int x = 0; x < nx; ++x) {
             const int k = tx[2 + x];
             h0 += (int)row[3 * x] * k;
             h1 += (int)row[3 * x + 1] * k;
