@@ -37,6 +37,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
                                               const u32x2 (*auxr)[4] = nullptr) {
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) bias = *(const float4*)(a.bias + n0);
+    // Guarded epilogues that ADD something per row (residual / position embedding): all of the lane's rows are requested first, with
+    // clamped row indices — a load behind the per-row guard makes hipcc wait vmcnt(0) in front of every store block, i.e. one serial
+    // round trip per row (20 of them in the patch-embedding launch, 4 in every small-M residual launch).
+    constexpr bool PRE = GUARD && (EPI == EPI_RESID_F32 || EPI == EPI_PATCH);
+    float4 pre[PRE ? MT : 1][4];
+    int prow[PRE ? MT : 1][4];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(rbase + mt * 16 + 4 * lg + r, M - 1);
+                prow[mt][r] = a.cmap ? a.cmap[m] : m;
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (EPI == EPI_PATCH) {
+                    const int m = min(rbase + mt * 16 + 4 * lg + r, M - 1);
+                    const int img = m / a.G2, p = m - img * a.G2;
+                    pre[mt][r] = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
+                } else pre[mt][r] = *(const float4*)(a.resid + (size_t)prow[mt][r] * a.ldr + n0);
+            }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -44,18 +69,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const f32x4 (&a
             const int m = rbase + mt * 16 + 4 * lg + r;
             if (GUARD && m >= M) continue;
             int pc = m, p2 = m;          // physical rows of C / resid and of C2 (row maps: small-M launches only)
-            if constexpr (GUARD) { if (a.cmap) pc = a.cmap[m]; if (a.c2map) p2 = a.c2map[m]; }
+            if constexpr (PRE) { pc = prow[mt][r]; if (a.c2map) p2 = a.c2map[m]; }
+            else if constexpr (GUARD) { if (a.cmap) pc = a.cmap[m]; if (a.c2map) p2 = a.c2map[m]; }
             float v0 = acc[mt][0][r] + bias.x, v1 = acc[mt][1][r] + bias.y, v2 = acc[mt][2][r] + bias.z, v3 = acc[mt][3][r] + bias.w;
             if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_PATCH) {
                 size_t orow = pc;
                 if constexpr (EPI == EPI_PATCH) {
                     int img = m / a.G2, p = m - img * a.G2;
                     orow = (size_t)img * a.T + 1 + p;
-                    float4 t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
+                    float4 t;
+                    if constexpr (PRE) t = pre[mt][r]; else t = *(const float4*)(a.pos + (size_t)(1 + p) * a.N + n0);
                     v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
                 if constexpr (EPI == EPI_RESID_F32) {
-                    float4 t = *(const float4*)(a.resid + (size_t)pc * a.ldr + n0);
+                    float4 t;
+                    if constexpr (PRE) t = pre[mt][r]; else t = *(const float4*)(a.resid + (size_t)pc * a.ldr + n0);
                     v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
                 }
                 st_out((f32x4*)((float*)a.C + orow * a.ldc + n0), f32x4{v0, v1, v2, v3});
