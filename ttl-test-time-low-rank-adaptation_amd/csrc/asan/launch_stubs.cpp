@@ -34,7 +34,8 @@ op_t to_op(float f) {       // bf16 round-to-nearest-even of the bits (the produ
 
 // ---------------------------------------------------------------- GEMM
 bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
-    if (epi == EPI_PATCH || epi == EPI_GELU_BWD) return false;
+    if (epi == EPI_PATCH) return false;
+    if (epi == EPI_GELU_BWD && (!a.aux || (size_t)((a.M + 127) / 128) * 128 > (size_t)a.padded)) return false;   // 128-row tiles, u read per tile
     if (a.M < 1024 || a.N % 256 || a.K % 64 || a.K / 64 < 3) return false;
     if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
     return true;
@@ -58,7 +59,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t) {
     const bool big = gemm_takes_big(epi, a);
     if (a.hm_T && !big) return hipErrorInvalidValue;
     // the big-M kernel reads A rows clamped to M-1 but STORES whole 160-row tiles (a.padded rows exist in every output buffer)
-    const long long rows_st = big ? (long long)((a.M + 159) / 160) * 160 : a.M;
+    const long long rows_st = !big ? a.M : epi == EPI_GELU_BWD ? (long long)((a.M + 127) / 128) * 128 : (long long)((a.M + 159) / 160) * 160;
     if (a.amap) { span_r(a.amap, (size_t)a.M * 4); for (int m : {0, a.M - 1}) mat_r(a.A + (size_t)a.amap[m] * a.lda, 1, a.K, a.lda, 2); }
     else mat_r(a.A, a.M, a.K, a.lda, 2);
     mat_r(a.B, a.N, a.K, a.ldb, 2);
@@ -84,7 +85,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t) {
         if (a.c2map) { span_r(a.c2map, (size_t)a.M * 4); for (int m : {0, a.M - 1}) mat_w(a.C2 + (size_t)a.c2map[m] * a.ldc2, 1, a.N, a.ldc2, 2); }
         else mat_w(a.C2, rows_st, a.N, a.ldc2, 2);
     }
-    if (epi == EPI_GELU_BWD) mat_r(a.aux, a.M, a.N, a.ldaux, 2);
+    if (epi == EPI_GELU_BWD) mat_r(a.aux, big ? rows_st : a.M, a.N, a.ldaux, 2);     // (the big-M kernel reads u of whole row tiles)
     if (a.M < 1024 && (epi == EPI_F32 || epi == EPI_RESID_F32) && a.ws && a.K >= 1536) span_w(a.ws, a.ws_bytes);
     return hipSuccess;
 }

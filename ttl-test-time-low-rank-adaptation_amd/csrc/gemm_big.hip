@@ -108,6 +108,8 @@ __device__ __forceinline__ void wait_dma() {
 // which drains that prefetch).  Register r of sub-tile (mt, nt) is row 16*mt + 4*lg + r, column 4*li + nt.
 constexpr int EPI_GELU_C2 = 100;   // internal: EPI_GELU with the second (pre-activation) output, kept branch-free
 constexpr int EPI_OP_HM = 101;     // internal: EPI_OP into a head-major q/k/v buffer (GemmArgs::hm_T, kernels.hpp QkvLayout)
+constexpr int EPI_GELU_BWD_BIG = 105;   // EPI_GELU_BWD (MLP dgrad: C = product * quick_gelu'(u)); u of the tile is read at the TOP of the tile
+                                        // into 8 * MT registers per lane and multiplied in at the end: 128-row tiles (MT = 4) keep that spill-free
 
 // Head-major q/k/v (EPI_OP_HM): the lane's 4 columns n0..n0+3 lie in one head, so their offset inside a view's block is a
 // per-tile constant (hm_col_base, computed once per tile) and a row adds view*3*D*T + t*64 with view = m / T by a multiply-high
@@ -121,7 +123,8 @@ __device__ __forceinline__ size_t hm_col_base(const GemmArgs& a, int n0) {
 }
 
 template <int EPI, int MT>
-__device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 (&acc)[MT][4], int mt, int rbase, size_t n0, int lg) {
+__device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 (&acc)[MT][4], int mt, int rbase, size_t n0, int lg,
+                                                 const u32x2 (*auxr)[4] = nullptr) {
     {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -138,6 +141,11 @@ __device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 
                     v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                     __builtin_nontemporal_store(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, (u32x2*)((op_t*)a.C + m * a.ldc + n0));
                 } else {
+                    if constexpr (EPI == EPI_GELU_BWD_BIG) {
+                        const u32x2 t = auxr[mt][r];
+                        v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
+                        v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
+                    }
                     st_out((u32x2*)((op_t*)a.C + m * a.ldc + n0), u32x2{pack_op2(v0, v1), pack_op2(v2, v3)});
                 }
             }
@@ -146,9 +154,10 @@ __device__ __forceinline__ void big_epilogue_row(const GemmArgs& a, const f32x4 
 }
 
 template <int EPI, int MT>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, size_t n0, int lg) {
+__device__ __forceinline__ void big_epilogue(const GemmArgs& a, const f32x4 (&acc)[MT][4], int rbase, size_t n0, int lg,
+                                             const u32x2 (*auxr)[4] = nullptr) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) big_epilogue_row<EPI, MT>(a, acc, mt, rbase, n0, lg);
+    for (int mt = 0; mt < MT; ++mt) big_epilogue_row<EPI, MT>(a, acc, mt, rbase, n0, lg, auxr);
 }
 
 struct TileMap {
@@ -253,7 +262,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
     };
     // the same while the previous tile's epilogue stores (at least NST of them, issued AFTER the K-tile waited for and
     // before the one left in flight) may still be unacknowledged: vmcnt counts loads and stores together, in order
-    constexpr int NST = 4 * MT;
+    // (+ the 4*MT ordinary loads the MLP-dgrad tile issues at its top for u: younger still, and counting them keeps this wait from
+    // also retiring K-tile 1 and the stores.  The residual tile's loads are not counted: their values are needed right behind the
+    // barrier anyway.)
+    constexpr int NST = 4 * MT + (EPI == EPI_GELU_BWD_BIG ? 4 * MT : 0);
+    static_assert(NPW + NST < 64, "vmcnt is a 6-bit counter");
     auto wait_tiles1_st = [&]() {
         if constexpr (NFULL != 0) { if (wave < NFULL) wait_dma<NPW + NST>(); else wait_dma<NPW - 1 + NST>(); }
         else wait_dma<NPW + NST>();
@@ -315,6 +328,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     rsd[mt][r] = *(const f32x4*)(a.resid + (size_t)(row0 + wm * WM + mt * 16 + 4 * lg + r) * a.ldr + col0 + wn * 64 + 4 * li);
+        }
+        u32x2 auxr[EPI == EPI_GELU_BWD_BIG ? MT : 1][4];
+        if constexpr (EPI == EPI_GELU_BWD_BIG) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    auxr[mt][r] = *(const u32x2*)(a.aux + (size_t)(row0 + wm * WM + mt * 16 + 4 * lg + r) * a.ldaux + col0 + wn * 64 + 4 * li);
         }
         char *cur = s0, *nxt = s1, *nn = s2;
         // K-tile 0 landed (STAGES == 3: K-tile 1 may still fly), and with it the bias piece (older than K-tile 0)
@@ -403,9 +424,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf0[mt], wf0[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(xf1[mt], wf1[nt], acc[mt][nt], 0, 0, 0);
-                    if (mt > 0) big_epilogue_row<EPI, MT>(a, acc, mt - 1, erow0 + wm * WM, ecol, lg);
+                    if (mt > 0) big_epilogue_row<EPI, MT>(a, acc, mt - 1, erow0 + wm * WM, ecol, lg, auxr);
                 }
-                big_epilogue_row<EPI, MT>(a, acc, MT - 1, erow0 + wm * WM, ecol, lg);
+                big_epilogue_row<EPI, MT>(a, acc, MT - 1, erow0 + wm * WM, ecol, lg, auxr);
             } else {
                 mma(xf0, wf0);
                 mma(xf1, wf1);
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
         } else if (!(TTL_BIG_EPI_OVERLAP && TTL_GEMM_DIAG == 0)) {
             size_t ecol = (size_t)(ecol0 + wn * 64 + 4 * li);
             if constexpr (EPI == EPI_OP_HM) ecol = hm_col_base(a, (int)ecol);
-            big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol, lg);
+            big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol, lg, auxr);
         }
         if (!more) break;
         slot = nslot;
@@ -478,7 +499,10 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
     if (epi == EPI_PATCH) return false;                       // scattered output rows: guarded kernel of gemm.hip
     // MLP dgrad: its epilogue reads u (8*MT registers fetched ahead in gemm.hip).  Tried here with u fetched behind the last
     // barrier: 82 us per launch vs 83-87 us on gemm.hip's kernel (the 77 MB read stays exposed either way) at the price of spills.
-    if (epi == EPI_GELU_BWD) return false;
+    if (epi == EPI_GELU_BWD) {      // 128-row tiles with u read at the top of the tile (TTL_GEMM_BIG_DGRAD=0: gemm.hip's 160 x 128 kernel)
+        static const bool on = [] { const char* v = getenv("TTL_GEMM_BIG_DGRAD"); return v ? atoi(v) != 0 : true; }();
+        if (!on || !a.aux || (size_t)((a.M + 127) / 128) * 128 > (size_t)a.padded) return false;
+    }
     if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3) return false;
     if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
     return true;
@@ -510,6 +534,10 @@ hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
             }
             return launch_big_v<EPI_OP>(a, mt, stages, order, max_blocks, s);
         case EPI_RESID_F32: return launch_big_v<EPI_RESID_F32>(a, mt, stages, order, max_blocks, s);
+        case EPI_GELU_BWD: {
+            const int ntm4 = (a.M + 127) / 128;
+            return launch_big_t<4, 3, EPI_GELU_BWD_BIG>(a, (ntm4 * ntn > cus) ? 1 : 2, max_blocks, s);
+        }
         case EPI_GELU: return a.C2 ? launch_big_v<EPI_GELU_C2>(a, mt, stages, order, max_blocks, s) : launch_big_v<EPI_GELU>(a, mt, stages, order, max_blocks, s);
         default: break;
     }
