@@ -14,11 +14,36 @@ from helpers import max_rel
 pytestmark = pytest.mark.gpu
 
 
+# Every kernel test runs on all three builds of the same sources (round-4 review, weak 4): "bf16" (libttl_hip.so), "fp16"
+# (libttl_hip_fp16.so — the headline build: other MFMA builtins, the dS * 2^8 pre-scale) and "strict" (libttl_hip_strict.so, the
+# test-only fp32 build).  TOL: what one rounding of an output / of P and dS to the operand type costs relative to the tensor's max.
+PRECISIONS = ("bf16", "fp16", "strict")
+TDT = {"bf16": torch.bfloat16, "fp16": torch.float16, "strict": torch.float32}
+OUT_TOL = {"bf16": 6e-3, "fp16": 8e-4, "strict": 2e-5}     # operand-dtype outputs (one rounding: 2^-8 / 2^-11 / none)
+BWD_TOL = {"bf16": 1e-2, "fp16": 1.5e-3, "strict": 5e-5}   # attention backward (P, dS and the outputs rounded)
+DS_PRESCALE = {"bf16": 1.0, "fp16": 256.0, "strict": 1.0}  # csrc/common.hpp TTL_DS_PRESCALE
+
+
+def op_round(a, prec):
+    """Round an fp32 array to the build's operand type and back (the rounding points of the MFMA path)."""
+    if prec == "bf16":
+        return O.bf16_round(a)
+    if prec == "fp16":
+        with np.errstate(over="ignore"):
+            return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    return np.asarray(a, np.float32)
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def prec(request):
+    return request.param
+
+
 @pytest.fixture(scope="module")
-def lib():
+def lib(prec):
     from ttl_amd import _lib
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    return _lib.load()
+    return _lib.load(prec)
 
 
 def P(t):
@@ -35,22 +60,22 @@ def chk(lib, rc):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 256, 768), (1000, 768, 832), (12608, 768, 768), (300, 3072, 768),
                                    (260, 768, 3072)])
-def test_gemm_bf16_nt(lib, M, N, K):
+def test_gemm_nt(lib, prec, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    b = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    a = torch.randn(M, K, generator=g).to(TDT[prec])
+    b = (torch.randn(N, K, generator=g) * 0.05).to(TDT[prec])
     # asymmetric integer-valued check first (guide: A=I style layout test)
-    ref = a.float().numpy() @ b.float().numpy().T
+    ref = (a.double().numpy() @ b.double().numpy().T).astype(np.float32)
     da, db = a.cuda(), b.cuda()
     c = torch.full((M, N), float("nan"), device="cuda")
     chk(lib, lib.ttl_gemm_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
     torch.cuda.synchronize()
     out = c.cpu().numpy()
     assert np.isfinite(out).all()
-    assert max_rel(out, ref) < 2e-5          # bf16 inputs exact, fp32 accumulate
+    assert max_rel(out, ref) < 2e-5          # operands exact in their type, fp32 accumulate
 
 
-def test_gemm_layout_asymmetric(lib):
+def test_gemm_layout_asymmetric(lib, prec):
     """C = I·B^T must reproduce an asymmetric B exactly (catches row/col swaps and k permutations)."""
     M = N = 128
     K = 128
@@ -58,7 +83,7 @@ def test_gemm_layout_asymmetric(lib):
     a[torch.arange(M), torch.arange(M) % K] = 1.0
     b = (torch.arange(N * K).reshape(N, K) % 251).float() - 100.0
     c = torch.empty(M, N, device="cuda")
-    da, db = a.to(torch.bfloat16).cuda(), b.to(torch.bfloat16).cuda()
+    da, db = a.to(TDT[prec]).cuda(), b.to(TDT[prec]).cuda()
     chk(lib, lib.ttl_gemm_nt(P(da), K, P(db), K, P(c), N, M, N, K, S()))
     torch.cuda.synchronize()
     assert np.array_equal(c.cpu().numpy(), (a @ b.T).numpy())
@@ -81,7 +106,7 @@ def test_layernorm(lib, rows, D):
     assert max_rel(rs.cpu().numpy(), rrs[:, 0]) < 1e-5
 
 
-def _attn_ref(qkv, n, T, H, causal=0):
+def _attn_ref(qkv, n, T, H, causal=0, prec="bf16"):
     D = H * 64
     x = qkv.reshape(n, T, 3, H, 64).transpose(2, 0, 3, 1, 4)        # [3,n,H,T,64]
     q, k, v = x[0], x[1], x[2]
@@ -92,30 +117,30 @@ def _attn_ref(qkv, n, T, H, causal=0):
     e = np.exp(s - m)
     den = e.sum(-1, keepdims=True)
     p = e / den
-    o = O.bf16_round(p) @ v
+    o = op_round(p, prec) @ v
     return q, k, v, p, o, (m + np.log(den))[..., 0]
 
 
 @pytest.mark.parametrize("n,T,H", [(44, 197, 12), (43, 200, 12), (64, 224, 8)])
-def test_attention_fwd_persistent_kernel(lib, n, T, H):
+def test_attention_fwd_persistent_kernel(lib, prec, n, T, H):
     """Launches of >= 512 (view, head) problems with 193 <= T <= 224 take attn_fwd_p_kernel (one workgroup per CU walking
     2-3 problems, next K/V/q prefetched by LDS-DMA behind counted waits): uneven problem counts per workgroup, padded and
     unpadded last key tile, with and without the log-sum-exp output (different store counts under the counted wait),
     bitwise repeatable."""
     D = H * 64
     g = torch.Generator().manual_seed(n + T)
-    qkv = (torch.randn(n * T, 3 * D, generator=g)).to(torch.bfloat16)
+    qkv = (torch.randn(n * T, 3 * D, generator=g)).to(TDT[prec])
     qkv[:, :D] *= 1.5
-    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, 0)
+    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, 0, prec)
     o_ref = o.transpose(0, 2, 1, 3).reshape(n * T, D)
     dq = qkv.cuda()
     outs = []
     for with_lse in (True, False, True):
-        out = torch.full((n * T, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+        out = torch.full((n * T, D), float("nan"), device="cuda", dtype=TDT[prec])
         lse = torch.empty(n, H, T, device="cuda")
         chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse) if with_lse else None, n, T, H, 0, S()))
         torch.cuda.synchronize()
-        assert max_rel(out.float().cpu().numpy(), o_ref) < 6e-3
+        assert max_rel(out.float().cpu().numpy(), o_ref) < OUT_TOL[prec]
         if with_lse:
             assert np.abs(lse.cpu().numpy() - lse_ref).max() < 2e-4
         outs.append(out)
@@ -124,42 +149,42 @@ def test_attention_fwd_persistent_kernel(lib, n, T, H):
 
 @pytest.mark.parametrize("n,T,H,causal", [(2, 17, 2, 0), (3, 197, 2, 0), (1, 257, 4, 0), (2, 50, 12, 0), (1, 150, 1, 0),
                                           (3, 77, 8, 1), (2, 77, 2, 1), (2, 17, 2, 1), (1, 197, 2, 1)])
-def test_attention_fwd_bwd(lib, n, T, H, causal):
+def test_attention_fwd_bwd(lib, prec, n, T, H, causal):
     D = H * 64
     g = torch.Generator().manual_seed(T)
-    qkv = (torch.randn(n * T, 3 * D, generator=g)).to(torch.bfloat16)
+    qkv = (torch.randn(n * T, 3 * D, generator=g)).to(TDT[prec])
     qkv[:, :D] *= 1.5
-    dout = (torch.randn(n * T, D, generator=g) * 0.1).to(torch.bfloat16)
-    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, causal)
-    out = torch.full((n * T, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dout = (torch.randn(n * T, D, generator=g) * 0.1).to(TDT[prec])
+    q, k, v, p, o, lse_ref = _attn_ref(qkv.float().numpy(), n, T, H, causal, prec)
+    out = torch.full((n * T, D), float("nan"), device="cuda", dtype=TDT[prec])
     lse = torch.empty(n, H, T, device="cuda")
     dq = qkv.cuda()
     ddo = dout.cuda()
     chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse), n, T, H, causal, S()))
     torch.cuda.synchronize()
     o_ref = o.transpose(0, 2, 1, 3).reshape(n * T, D)
-    assert max_rel(out.float().cpu().numpy(), o_ref) < 6e-3          # bf16 output rounding
+    assert max_rel(out.float().cpu().numpy(), o_ref) < OUT_TOL[prec]          # output rounded to the operand type
     assert np.abs(lse.cpu().numpy() - lse_ref).max() < 2e-4
     # backward, from the kernel's own (rounded) output like the real path
     o_k = out.float().cpu().numpy().reshape(n, T, H, 64).transpose(0, 2, 1, 3)
     dO = dout.float().numpy().reshape(n, T, H, 64).transpose(0, 2, 1, 3)
     delta = (dO * o_k).sum(-1, keepdims=True)
-    dV = O.bf16_round(p).transpose(0, 1, 3, 2) @ dO
+    dV = op_round(p, prec).transpose(0, 1, 3, 2) @ dO
     dP = dO @ v.transpose(0, 1, 3, 2)
-    dS = O.bf16_round(p * (dP - delta))
+    dS = op_round(p * (dP - delta) * DS_PRESCALE[prec], prec) / DS_PRESCALE[prec]      # (fp16: rounded as dS * 2^8, common.hpp)
     dQ = (dS @ k) * 0.125
     dK = (dS.transpose(0, 1, 3, 2) @ q) * 0.125
     mg = lambda a: a.transpose(0, 2, 1, 3).reshape(n * T, D)
     ld = 3 * D + 64
     for need_dk in (1, 0):
-        dqkv = torch.zeros(n * T, ld, device="cuda", dtype=torch.bfloat16)
+        dqkv = torch.zeros(n * T, ld, device="cuda", dtype=TDT[prec])
         chk(lib, lib.ttl_attention_bwd(P(dq), P(out), P(ddo), P(lse), P(dqkv), ld, n, T, H, need_dk, causal, S()))
         torch.cuda.synchronize()
         r = dqkv.float().cpu().numpy()
-        assert max_rel(r[:, :D], mg(dQ)) < 1e-2
-        assert max_rel(r[:, 2 * D:3 * D], mg(dV)) < 1e-2
+        assert max_rel(r[:, :D], mg(dQ)) < BWD_TOL[prec]
+        assert max_rel(r[:, 2 * D:3 * D], mg(dV)) < BWD_TOL[prec]
         if need_dk:
-            assert max_rel(r[:, D:2 * D], mg(dK)) < 1e-2
+            assert max_rel(r[:, D:2 * D], mg(dK)) < BWD_TOL[prec]
         else:
             assert not r[:, D:2 * D].any()
         assert not r[:, 3 * D:].any()
@@ -273,17 +298,17 @@ def test_adamw_vs_torch_reference(lib, unit):
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(12608, 2304, 832), (12608, 768, 3072), (12608, 3072, 768), (2056, 1024, 1024), (1500, 256, 192),
                                    (16448, 1024, 4096)])
-def test_gemm_big_tiles_with_fused_epilogues(lib, M, N, K, epi):
+def test_gemm_big_tiles_with_fused_epilogues(lib, prec, M, N, K, epi):
     """The big-M kernel of gemm_big.hip (160x256x64 tiles, persistent blocks, 3-stage DMA ring, bias / residual folded into
     the accumulator init) through ttl_gemm_nt_epi: every epilogue the episode uses, row counts that end inside the last
     row tile, one / several tiles per block, odd K-tile counts — against an fp32 matmul of the same bf16 operands."""
     g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
-    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
-    b = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    a = torch.randn(M, K, generator=g).to(TDT[prec]).cuda()
+    b = (torch.randn(N, K, generator=g) * 0.05).to(TDT[prec]).cuda()
     bias = torch.randn(N, generator=g).cuda()
     Mp = (M + 1279) // 1280 * 1280
     res = torch.randn(Mp, N, generator=g).cuda() if epi == 2 else None
-    c = torch.full((Mp, N), 7.0, device="cuda", dtype=torch.float32 if epi in (0, 2) else torch.bfloat16)
+    c = torch.full((Mp, N), 7.0, device="cuda", dtype=torch.float32 if epi in (0, 2) else TDT[prec])
     chk(lib, lib.ttl_gemm_nt_epi(P(a), K, P(b), K, P(c), N, M, N, K, epi, P(bias), P(res) if res is not None else None, N, Mp, S()))
     torch.cuda.synchronize()
     want = a.float() @ b.float().t() + bias
@@ -292,15 +317,15 @@ def test_gemm_big_tiles_with_fused_epilogues(lib, M, N, K, epi):
     if epi == 3:
         want = want * torch.sigmoid(1.702 * want)
     got = c[:M].float()
-    tol = 2e-5 if epi in (0, 2) else 6e-3        # fp32 out: accumulation order only; operand-dtype out: one bf16 rounding
+    tol = 2e-5 if epi in (0, 2) else OUT_TOL[prec]        # fp32 out: accumulation order only; operand-dtype out: one rounding
     assert max_rel(got.cpu().numpy(), want.cpu().numpy()) < tol
-    # rows of the arena padding beyond round_up(M, 160) are never written
+    # rows of the arena padding beyond round_up(M, 160) are never written (strict build: beyond M)
     top = (M + 159) // 160 * 160
     if top < Mp:
         assert (c[top:].float() == 7.0).all()
 
 
-def test_gradscaler_known_answers(lib):
+def test_gradscaler_known_answers(lib, prec):
     """ttl_scaler_config / ttl_scaler_unscale / ttl_optimizer_step against the reference's own objects — torch.amp.GradScaler(
     init_scale=1000) around torch.optim.AdamW — over 9 updates with an inf and a nan injected (fixture written by
     tests/golden/make_gradscaler_golden.py): the WHOLE step is skipped on a non-finite gradient (params, exp_avg, exp_avg_sq
@@ -310,7 +335,7 @@ def test_gradscaler_known_answers(lib):
     from ttl_amd.config import get_config
     from ttl_amd.engine import TTLEngine
     u = np.load(os.path.join(GOLDEN, "unit_gradscaler.npz"))
-    eng = TTLEngine(get_config("tiny"), 4, 10, "cuda:0")
+    eng = TTLEngine(get_config("tiny"), 4, 10, "cuda:0", precision=prec)
     eng.scaler_config(True, float(u["init_scale"]), float(u["growth_factor"]), float(u["backoff_factor"]), int(u["growth_interval"]))
     p = torch.from_numpy(u["p0"]).cuda()
     m, v = torch.zeros_like(p), torch.zeros_like(p)
@@ -328,3 +353,30 @@ def test_gradscaler_known_answers(lib):
         np.testing.assert_allclose(v.cpu().numpy(), u["v"][t], rtol=2e-5, atol=1e-12)
     assert eng.scaler_state()["skipped_steps"] == 2
     eng.close()
+
+
+def test_fp16_prescaled_ds_overflow_is_an_inf_not_a_wrong_number():
+    """fp16 build only (csrc/common.hpp:16-23): dS is rounded to fp16 as dS * 2^8.  When |dP| is large enough that the pre-scaled
+    value exceeds fp16's range, the overflow must surface as inf / nan in dQ and dK — which the gradient reduction turns into
+    found_inf, a skipped step and a halved loss scale (test_gpu_path.py::test_overflowing_backward_skips_the_whole_step_and_halves_
+    the_scale) — never as a saturated finite number.  dV = P^T dO does not go through dS and stays finite."""
+    from ttl_amd import _lib
+    lib = _lib.load("fp16")
+    n, T, H = 2, 50, 2
+    D = H * 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(n * T, 3 * D, generator=g).to(torch.float16)
+    qkv[:, :D] *= 3.0                                   # peaked rows: P close to one-hot, so dS ~ dP
+    dq = qkv.cuda()
+    out = torch.empty(n * T, D, device="cuda", dtype=torch.float16)
+    lse = torch.empty(n, H, T, device="cuda")
+    chk(lib, lib.ttl_attention_fwd(P(dq), P(out), P(lse), n, T, H, 0, S()))
+    ld = 3 * D + 64
+    for mag, overflow in ((1.0, False), (400.0, True)):  # |dP| ~ mag * 8 * |v|: 400 -> dS * 2^8 ~ 1e6 >> 65504
+        dout = (torch.randn(n * T, D, generator=g) * mag).to(torch.float16).cuda()
+        dqkv = torch.zeros(n * T, ld, device="cuda", dtype=torch.float16)
+        chk(lib, lib.ttl_attention_bwd(P(dq), P(out), P(dout), P(lse), P(dqkv), ld, n, T, H, 1, 0, S()))
+        torch.cuda.synchronize()
+        r = dqkv.float().cpu().numpy()
+        assert np.isfinite(r[:, 2 * D:3 * D]).all()                       # dV
+        assert np.isfinite(r[:, :2 * D]).all() == (not overflow), mag     # dQ, dK

@@ -267,10 +267,11 @@ size_t ttl_workspace_bytes(const ttl_config* k) {
     ttl_ctx t; set_geometry(&t, k);
     size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nS, N = k->max_views;   // (saved layers: layer_lo..L-1)
     const size_t ldo = D + (t.has_o ? 64 : 0);
-    size_t w = L * (3 * D * t.ldw + D * ldo + 2 * D * F) * 2 + nT * (D * t.ldwt + D * ldo + 2 * D * F) * 2 + D * t.Kp * 2 + 2 * t.E * D * 4 +
+    const size_t ob = sizeof(op_t);    // bytes per operand element (2; 4 in the strict build)
+    size_t w = L * (3 * D * t.ldw + D * ldo + 2 * D * F) * ob + nT * (D * t.ldwt + D * ldo + 2 * D * F) * ob + D * t.Kp * ob + 2 * t.E * D * 4 +
                (t.text ? (size_t)k->vocab_size * D * 4 : 0);
-    size_t act = (size_t)N * t.G2 * t.Kp * 2 + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + (M + t.T) * 3 * D + M * ldo + M * F) * 2 +
-                 (M * D + (M + t.T) * 3 * D + M * D + M * D + M * F) * 2 + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * 2 +
+    size_t act = (size_t)N * t.G2 * t.Kp * ob + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + (M + t.T) * 3 * D + M * ldo + M * F) * ob +
+                 (M * D + (M + t.T) * 3 * D + M * D + M * D + M * F) * ob + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * ob +
                  (size_t)lora_wgrad_chunks((int)M) * 2 * t.ntg * t.r * D * 4;
     return w + act;
 }
@@ -1214,6 +1215,7 @@ static int episode_tail(ttl_ctx* c, const ttl_episode_args* a, const float* logi
 int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (!c || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
     if (c->text) return fail(TTL_ESTATE, "ttl_episode on a text-tower context (use ttl_episode_text)");
+    if ((a->target == nullptr) != (a->hits_out == nullptr)) return fail(TTL_EINVAL, "target and hits_out go together");   // before the first launch
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -1295,6 +1297,7 @@ void ttl_graph_destroy(ttl_graph* g) {
 int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* stream) {
     if (!c || !v || !a || !a->x || !a->snapshot || !a->exp_avg || !a->exp_avg_sq || !a->logits1_out) return fail(TTL_EINVAL, "null argument");
     if (!c->text || v->text) return fail(TTL_ESTATE, "ttl_episode_text(text_ctx, image_ctx, ...): wrong tower kinds");
+    if ((a->target == nullptr) != (a->hits_out == nullptr)) return fail(TTL_EINVAL, "target and hits_out go together");   // before the first launch
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called on the text context");
     if (c->n_prompts < 1) return fail(TTL_ESTATE, "ttl_set_prompts has not been called");
     if (a->n_views > c->c.max_classes) return fail(TTL_EINVAL, "n_views %d exceeds the text context's capacity %d", a->n_views, c->c.max_classes);
@@ -1414,17 +1417,17 @@ int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t by
     else if (nm == "n_selected") { src = c->n_buf; have = 4; }
     else if (nm == "entropy") { src = c->H_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 4; }
     else if (nm == "dh") { src = c->dh; have = M * D * 4; }
-    else if (nm == "dqkv") { src = c->dqkv; have = M * c->ldwt * 2; }
+    else if (nm == "dqkv") { src = c->dqkv; have = M * c->ldwt * sizeof(op_t); }
     else if (!tr) return fail(TTL_EINVAL, "%s: layer %d is not a trained (saved) layer", name, layer);
     else {
         Layer& l = c->layers[layer];
         if (nm == "h_in") { src = l.h_in; have = M * D * 4; }
         else if (nm == "h_mid") { src = l.h_mid; have = M * D * 4; }
         else if (nm == "h_out") { src = c->h_out[layer - c->c.layer_lo]; have = M * D * 4; }
-        else if (nm == "qkv") { src = l.qkv; have = M * 3 * D * 2; }
-        else if (nm == "attn_out") { src = l.attn; have = M * l.ldat * 2; }
-        else if (nm == "x1") { src = l.x1ext; have = M * c->ldx * 2; }
-        else if (nm == "u") { src = l.u; have = M * F * 2; }
+        else if (nm == "qkv") { src = l.qkv; have = M * 3 * D * sizeof(op_t); }
+        else if (nm == "attn_out") { src = l.attn; have = M * l.ldat * sizeof(op_t); }
+        else if (nm == "x1") { src = l.x1ext; have = M * c->ldx * sizeof(op_t); }
+        else if (nm == "u") { src = l.u; have = M * F * sizeof(op_t); }
         else if (nm == "lse") { src = l.lse; have = (size_t)c->saved_n * c->H * c->T * 4; }
         else return fail(TTL_EINVAL, "unknown buffer %s", name);
     }

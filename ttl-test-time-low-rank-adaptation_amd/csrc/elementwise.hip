@@ -13,7 +13,8 @@ __global__ void cast_kernel(const float* __restrict__ src, op_t* __restrict__ ds
     size_t stride = (size_t)gridDim.x * blockDim.x * 8;
     for (; i + 8 <= n; i += stride) {
         float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
-        *(u32x4*)(dst + i) = u32x4{pack_op2(a.x, a.y), pack_op2(a.z, a.w), pack_op2(b.x, b.y), pack_op2(b.z, b.w)};
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        st_op8(dst + i, v);
     }
     // tail (n % 8) handled by the first thread
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -64,7 +65,7 @@ __global__ void im2col_kernel(const float* __restrict__ x, op_t* __restrict__ ou
     if (P % 8 == 0) {
         int gx = xs / P, px = xs - gx * P;
         op_t* d = out + ((size_t)(img * G + gy) * G + gx) * Kp + (c * P + py) * P + px;
-        *(u32x4*)d = u32x4{pack_op2(v[0], v[1]), pack_op2(v[2], v[3]), pack_op2(v[4], v[5]), pack_op2(v[6], v[7])};
+        st_op8(d, v);
     } else {  // P = 14 (ViT-L/14): 8-pixel groups straddle patches
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 float o0 = (v[r][i].x - mu) * rs * g.x + b.x, o1 = (v[r][i].y - mu) * rs * g.y + b.y;
                 float o2 = (v[r][i].z - mu) * rs * g.z + b.z, o3 = (v[r][i].w - mu) * rs * g.w + b.w;
                 if (y32) *(float4*)(y32 + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
-                if (y16) *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+                if (y16) st_op4(y16 + (size_t)row * ld16 + 4 * c, o0, o1, o2, o3);
             }
         }
     }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) LN_PERSIST_ATTR void ln_fwd_persist_kernel(con
                 const float4 gg = LN_G(i), bb = LN_B(i);
                 const float o0 = (cur[i].x - mu) * rs * gg.x + bb.x, o1 = (cur[i].y - mu) * rs * gg.y + bb.y;
                 const float o2 = (cur[i].z - mu) * rs * gg.z + bb.z, o3 = (cur[i].w - mu) * rs * gg.w + bb.w;
-                *(u32x2*)(y16 + (size_t)row * ld16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+                st_op4(y16 + (size_t)row * ld16 + 4 * c, o0, o1, o2, o3);
             }
         }
 #pragma unroll
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             float o0 = r.x + rs * (dxh[i].x - m1 - xh[i].x * m2), o1 = r.y + rs * (dxh[i].y - m1 - xh[i].y * m2);
             float o2 = r.z + rs * (dxh[i].z - m1 - xh[i].z * m2), o3 = r.w + rs * (dxh[i].w - m1 - xh[i].w * m2);
             if (o32) *(float4*)(o32 + (size_t)row * os + 4 * c) = make_float4(o0, o1, o2, o3);
-            if (o16) *(u32x2*)(o16 + (size_t)row * os16 + 4 * c) = u32x2{pack_op2(o0, o1), pack_op2(o2, o3)};
+            if (o16) st_op4(o16 + (size_t)row * os16 + 4 * c, o0, o1, o2, o3);
         }
     }
 }
@@ -433,7 +434,8 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
 #if TTL_LN_VARIANT == 2
     if (rows >= 4096 && !y_f32 && y_bf16 && !rowmap && row_stride == D) {
         const int cus = device_cu_count();
-        static const int pblk = [] { const char* v = getenv("TTL_LN_PBLK"); return v ? atoi(v) : 8; }();
+        if (!cus) return hipErrorInvalidDevice;
+        static const int pblk = [] { const char* v = getenv("TTL_LN_PBLK"); const int b = v ? atoi(v) : 8; return b < 1 ? 1 : b; }();
         if (D <= 768) hipLaunchKernelGGL(ln_fwd_persist_kernel<3>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
         else hipLaunchKernelGGL(ln_fwd_persist_kernel<4>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
         return hipGetLastError();

@@ -46,6 +46,45 @@ __global__ void refresh_kernel(LoraPtrs P, int3 slot /* of q, k, v; -1 = none */
     }
 }
 
+#ifdef TTL_OPERAND_FP32
+// ---- strict (fp32) build: the same product in plain fp32 FMAs.  One wave per SK32_ROWS rows of X; lane l owns elements
+// d = l, l + 64, ... of every row (held in registers), walks the output columns and reduces across the wave.
+constexpr int SK32_ROWS = 4, SK32_MAXC = 16;     // D <= 1024
+__global__ __launch_bounds__(256) void skinny_f32_kernel(const op_t* __restrict__ X, long long ldx, int3 xoff, int r,
+                                                          const op_t* __restrict__ Wcat, int D, float scale,
+                                                          op_t* __restrict__ out, long long ldo, int M, const int* __restrict__ rowmap) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.y;
+    const int xo = t == 0 ? xoff.x : t == 1 ? xoff.y : xoff.z;
+    const int m0 = (blockIdx.x * 4 + wave) * SK32_ROWS;
+    if (m0 >= M) return;
+    const int nc = D >> 6;
+    long long prow[SK32_ROWS];
+    float x[SK32_ROWS][SK32_MAXC];
+#pragma unroll
+    for (int i = 0; i < SK32_ROWS; ++i) {
+        const int row = min(m0 + i, M - 1);
+        prow[i] = rowmap ? rowmap[row] : row;
+#pragma unroll
+        for (int c = 0; c < SK32_MAXC; ++c) x[i][c] = c < nc ? X[prow[i] * ldx + xo + lane + 64 * c] : 0.f;
+    }
+    for (int col = 0; col < r; ++col) {
+        const op_t* w = Wcat + (size_t)(t * r + col) * D;
+        float acc[SK32_ROWS] = {};
+#pragma unroll
+        for (int c = 0; c < SK32_MAXC; ++c) {
+            const float wv = c < nc ? w[lane + 64 * c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < SK32_ROWS; ++i) acc[i] = fmaf(x[i][c], wv, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SK32_ROWS; ++i) {
+            const float v = wave_sum(acc[i]);
+            if (lane == 0 && m0 + i < M) out[prow[i] * ldo + t * r + col] = v * scale;
+        }
+    }
+}
+#else
 // One wave: 16 rows of X times the r columns of ONE adapter (blockIdx.y = slot of the adapter).  MFMA A operand = Wcat rows
 // (output row = column c of the result), B operand = X rows (output column = token) -> each lane ends with 4 consecutive
 // result columns of one token: one 8-byte store.  The kernel is pure latency (a few hundred waves, each a serial K loop), so
@@ -120,10 +159,42 @@ __global__ __launch_bounds__(64 * SK_WPB) void skinny_kernel(const op_t* __restr
     }
 }
 
+#endif  // TTL_OPERAND_FP32 (skinny)
+
 // ---- weight gradients: partial[prod][chunk][r][D] = S_chunk^T · G_chunk over 256-token chunks
 constexpr int WG_CH = 256;   // tokens per chunk
 constexpr int WG_BN = 128;   // result columns per block
 
+#ifdef TTL_OPERAND_FP32
+// ---- strict (fp32) build: the same chunked product in fp32 FMAs.  Block = one 256-token chunk x 128 result columns; the S chunk
+// [256][R] sits in LDS, thread t owns column n0 + t % 128 and the rows j = (t / 128) * R/2 .. of the result.
+template <int R>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, int D, float* __restrict__ partial, int nch, int prod0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sS = (float*)smem;      // [256][R]
+    const int tid = threadIdx.x;
+    const int ch = blockIdx.x, cb = blockIdx.y, prod = prod0 + blockIdx.z;
+    const int m0 = ch * WG_CH, n0 = cb * WG_BN;
+    const op_t* S = L.p[prod].S; const long long lds_ = L.p[prod].lds;
+    const op_t* G = L.p[prod].G; const long long ldg = L.p[prod].ldg;
+    for (int q = tid; q < WG_CH * R; q += 256) {
+        const int rr = q / R, c = q - rr * R;
+        sS[q] = (m0 + rr < M) ? S[(long long)(m0 + rr) * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    const int col = n0 + (tid & 127), j0 = (tid >> 7) * (R / 2);
+    float acc[R / 2] = {};
+    const int rows = min(WG_CH, M - m0);
+    for (int m = 0; m < rows; ++m) {
+        const float g = G[(long long)(m0 + m) * ldg + col];
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) acc[j] = fmaf(sS[m * R + j0 + j], g, acc[j]);
+    }
+    float* po = partial + L.p[prod].poff + (size_t)ch * R * D;
+#pragma unroll
+    for (int j = 0; j < R / 2; ++j) po[(size_t)(j0 + j) * D + col] = acc[j];
+}
+#else
 __device__ __forceinline__ int wg_u(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <int R>
@@ -206,6 +277,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
                 po[(size_t)(a * 16 + 4 * lg + e) * D + n0 + 32 * wave + 16 * b + li] = acc[a][b][e];
 }
 
+#endif  // TTL_OPERAND_FP32 (wgrad)
+
 // 64 outputs x 4 chunk-slices per block: slice q sums chunks q, q+4, ... in order, the four slice sums are added in a
 // fixed order -> deterministic; one thread walking all ~50 chunks serially left the 9.8 MB read latency-bound (16 us)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nch, int D, int r, const WgradList L,
@@ -256,6 +329,7 @@ hipError_t launch_lora_refresh(const LoraPtrs& P, int D, int r, op_t* wqkv_ext, 
     return hipGetLastError();
 }
 
+#ifndef TTL_OPERAND_FP32
 template <int NCG, int KS>
 static hipError_t skinny_launch(const op_t* X, long long ldx, int3 xoff, int ntg, const op_t* W, int D, float scale, op_t* out,
                                 long long ldo, int M, hipStream_t s, const int* rowmap) {
@@ -267,6 +341,8 @@ static hipError_t skinny_launch(const op_t* X, long long ldx, int3 xoff, int ntg
     return hipGetLastError();
 }
 
+#endif
+
 hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int ntg, const op_t* Wcat, int D, int r, float scale,
                               op_t* out, long long ldo, int M, hipStream_t s, const int* rowmap) {
     if (ntg < 1 || ntg > 3) return hipErrorInvalidValue;
@@ -274,6 +350,12 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
     { static std::atomic<int> cnt{0}; if ((TTL_DIAG_SKIP & 1) && M >= 4096 && diag_skip_now(cnt, 360)) return hipSuccess; }
 #endif
     int3 xo = {xoff[0], ntg > 1 ? xoff[1] : 0, ntg > 2 ? xoff[2] : 0};
+#ifdef TTL_OPERAND_FP32
+    if (D % 64 || D > 64 * SK32_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(skinny_f32_kernel, dim3((M + 4 * SK32_ROWS - 1) / (4 * SK32_ROWS), ntg), dim3(256), 0, s, X, ldx, xo, r, Wcat, D, scale,
+                       out, ldo, M, rowmap);
+    return hipGetLastError();
+#else
     int ncg = r / 16;
     const int ks = D / 32;
     // Adapters that read the SAME columns of X (the forward's down-projections U_t = s x A_t^T of q / k / v: every xoff 0) are one
@@ -290,9 +372,12 @@ hipError_t launch_lora_skinny(const op_t* X, long long ldx, const int* xoff, int
     SK(1, 4);  SK(2, 4); SK(3, 4); SK(4, 4); SK(6, 4);          // reduced test geometry (D = 128)
 #undef SK
     return hipErrorInvalidValue;
+#endif
 }
 
 int lora_wgrad_chunks(int M) { return (M + WG_CH - 1) / WG_CH; }
+// dynamic LDS of wgrad_kernel<R>: the G tile + the S tile in the operand type (16-bit builds); the S chunk in fp32 (strict build)
+static constexpr int wgrad_smem(int R) { return sizeof(op_t) == 4 ? WG_CH * R * 4 : WG_CH * WG_BN * 2 + WG_CH * R * 2; }
 
 hipError_t launch_lora_wgrad(const WgradList& L0, int M, int D, int r, float* partial, hipStream_t s, const float* scaler_f, int* scaler_i) {
     if (D % WG_BN || L0.n < 1 || L0.n > WGRAD_MAX) return hipErrorInvalidValue;
@@ -334,13 +419,13 @@ hipError_t launch_lora_wgrad(const WgradList& L0, int M, int D, int r, float* pa
     for (int i = 0; i < L.n; ++i) { L.p[i].poff = off; off += (size_t)nch * L.p[i].rows * D; }
     auto launch = [&](auto kern, int R, int prod0, int count) -> hipError_t {
         if (count <= 0) return hipSuccess;
-        const int SMEM = WG_CH * WG_BN * 2 + WG_CH * R * 2;
+        const int SMEM = wgrad_smem(R);
         hipLaunchKernelGGL(kern, dim3(nch, D / WG_BN, count), dim3(256), SMEM, s, L, M, D, partial, nch, prod0);
         return hipGetLastError();
     };
     static std::atomic<uint64_t> done16{0}, done32{0};
-    hipError_t e = ensure_smem((const void*)wgrad_kernel<16>, WG_CH * WG_BN * 2 + WG_CH * 16 * 2, done16);
-    if (e == hipSuccess) e = ensure_smem((const void*)wgrad_kernel<32>, WG_CH * WG_BN * 2 + WG_CH * 32 * 2, done32);
+    hipError_t e = ensure_smem((const void*)wgrad_kernel<16>, wgrad_smem(16), done16);
+    if (e == hipSuccess) e = ensure_smem((const void*)wgrad_kernel<32>, wgrad_smem(32), done32);
     if (e != hipSuccess) return e;
     if (r == 16) {
         if ((e = launch(wgrad_kernel<32>, 32, 0, nm)) != hipSuccess) return e;
@@ -348,6 +433,8 @@ hipError_t launch_lora_wgrad(const WgradList& L0, int M, int D, int r, float* pa
     } else if (r == 32) {
         if ((e = launch(wgrad_kernel<32>, 32, 0, L.n)) != hipSuccess) return e;
     } else return hipErrorInvalidValue;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((2 * r * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);
+    int maxrows = r;      // result rows of the widest product (2r only when two products were merged)
+    for (int i = 0; i < L.n; ++i) maxrows = L.p[i].rows > maxrows ? L.p[i].rows : maxrows;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((maxrows * D + 63) / 64, L.n), dim3(256), 0, s, partial, nch, D, r, L, scaler_f, scaler_i);
     return hipGetLastError();
 }

@@ -10,7 +10,11 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libttl_hip.so")            # bf16 operands (default; BASELINE north_star)
-LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libttl_hip_fp16.so")}   # same ABI, operand dtype differs
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libttl_hip_fp16.so"),   # same ABI, operand dtype differs
+             # TEST-ONLY strict-precision build (fp32 operand buffers, fp32 products; csrc/common.hpp TTL_OPERAND_FP32): what the
+             # parity tests hold against the reference's fp32 path at 1e-5 / 1e-4; never benched, never a default
+             "strict": os.path.join(_HERE, "libttl_hip_strict.so")}
+OPERAND_DTYPE = {"bf16": "bf16", "fp16": "fp16", "strict": "fp32"}    # what ttl_operand_dtype() of each build answers
 # A/B timing of experimental builds (tools/): another build of the same ABI for one operand dtype.  bench.py refuses to run under
 # such an override unless --variant-lib is passed, and records path + sha256 of what it loaded either way.
 for _prec, _var in (("bf16", "TTL_HIP_LIB_BF16"), ("fp16", "TTL_HIP_LIB_FP16")):
@@ -140,8 +144,8 @@ def load(precision="bf16"):
     if missing:
         raise TtlError(f"{path} does not export: {', '.join(missing)}")
     got = lib.ttl_operand_dtype().decode()
-    if got != precision:
-        raise TtlError(f"{path} was built for {got} operands, expected {precision}")
+    if got != OPERAND_DTYPE[precision]:
+        raise TtlError(f"{path} was built for {got} operands, expected {OPERAND_DTYPE[precision]}")
     _libs[precision] = lib
     return lib
 
