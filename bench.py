@@ -40,8 +40,9 @@ def parse_args():
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-staged view batches per rank")
     ap.add_argument("--streams", type=int, default=3, help="independent episodes in flight per GPU (HIP streams)")
-    ap.add_argument("--precision", default="auto", choices=["auto", "bf16", "fp16"],
-                    help="MFMA operand dtype.  auto (default): BOTH builds are timed under one protocol (same steps / warm-up / repeats / "
+    ap.add_argument("--precision", default=None, choices=["auto", "bf16", "fp16"],
+                    help="MFMA operand dtype.  Default: auto with --gpus 1, fp16 (the headline build alone: half the warm-up and the memory of "
+                         "8 ranks x 2 builds) with --gpus N > 1 unless auto is asked for explicitly.  auto: BOTH builds are timed under one protocol (same steps / warm-up / repeats / "
                          "graph regime, blocks interleaved) and the headline is the build that meets the north_star's tolerance on the "
                          "reference-generated fixture (selection mask exact, logits within 1e-3): fp16 operands, the reference's own "
                          "autocast dtype (ttl.py:79); the other build is reported under its own key.  bf16 / fp16: that build only")
@@ -62,7 +63,17 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for smoke-testing the N>1 logic on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="smoke test: put every rank on cuda:0 (with --backend gloo)")
-    return ap.parse_args()
+    ap.add_argument("--stub-pipeline", action="store_true",
+                    help="TEST HOOK (tests/test_dist_gloo_cpu.py): the control flow of an N-rank run — self-spawn, ranks_seen, interleaved timed "
+                         "blocks, per-rank rates, rank_balance, the JSON line — with a host-only stand-in for the episode pipeline (sleeps "
+                         "TTL_BENCH_STUB_MS per image; TTL_BENCH_STUB_SLOW='rank:factor' slows one rank), gloo on CPU, no GPU, no library.  "
+                         "The line says `stub: true`; it is not a measurement")
+    a = ap.parse_args()
+    if a.precision is None:
+        a.precision = "auto" if a.gpus <= 1 else "fp16"
+    if a.stub_pipeline:
+        a.backend, a.no_parity, a.no_cpu_baseline, a.no_pin = "gloo", True, True, True
+    return a
 
 
 def self_spawn(a):
@@ -75,7 +86,15 @@ def self_spawn(a):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd))
+    # torch.distributed.run turns any failing rank into its own exit code 1: rank 0 leaves the code it meant (3 = --strict-balance
+    # tripped) in a status file, so that `python bench.py --gpus N --strict-balance` exits with it
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        status = os.path.join(td, "exit_code")
+        rc = subprocess.call(cmd, env=dict(os.environ, TTL_BENCH_STATUS_FILE=status))
+        if rc and os.path.exists(status):
+            rc = int(open(status).read().strip() or rc)
+    raise SystemExit(rc)
 
 
 def episode_flops(cfg, n_views, n_classes):
@@ -178,7 +197,10 @@ def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
 
 def parity_check(precision):
     """Untimed: the reference-generated fixture b16_n64_k200_ent0 (ViT-B/16, 64 views, K=200: the benched workload's
-    shape) through the build for `precision`.  metric = max|a-b| / max|b| per tensor (tests/helpers.max_rel)."""
+    shape) through the build for `precision`.  metric = max|a-b| / max|b| per tensor (tests/helpers.max_rel).
+    precision == "strict": the test-only fp32 build (libttl_hip_strict.so: same launch sequences, LayerNorm / head / loss /
+    optimizer kernels; fp32 products) held to the tolerance BY THE LETTER — logits 1e-5, every gradient tensor 1e-4, post-step
+    weights 1e-3 element-wise with no allowance for the measured gradient error (tests/test_gpu_strict.py has the same rule)."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -201,6 +223,8 @@ def parity_check(precision):
     grads, off, gerr, werr, wfar, wn = eng.grads.cpu().numpy(), 0, 0.0, 0.0, 0, 0
     new = flat.cpu().numpy()
     tol = 1e-3
+    strict = precision == "strict"
+    steep_exempt = hard = 0      # strict build: elements beyond tolerance inside / outside the eps-steep region of the sign-like step
     # norm-wise figures beside the element-wise ones (SURVEY 7.2 "relative Frobenius norm"): ||a-b||_F / ||b||_F over ALL the
     # trainable tensors; for the post-step weights both of the weights themselves and of the UPDATE (new - initial), which is
     # what the step produced (B starts at 0, so for B the two coincide; A moves by lr*wd only, Q11)
@@ -218,6 +242,17 @@ def parity_check(precision):
         du2 += float((d ** 2).sum()); ru2 += float(((wref - w0) ** 2).sum())
         werr = max(werr, float(d.max()))
         wfar += int((d > tol * np.abs(wref).max()).sum())
+        if strict and np.abs(gref).max() > 0:
+            # f(g) = -lr g / (|g| + eps) is so steep for |g| within a few eps = 1e-8 of zero that fp32 summation noise of the
+            # gradient (1e-5 of its max: ten times below the gradient tolerance) moves the element by more than the weight
+            # tolerance; such an element is exempt only if its own gradient agrees with the reference's to that noise
+            gr = np.asarray(gref, np.float64)
+            dgn = 1e-5 * np.abs(gr).max()
+            f = lambda t: -kw["lr"] * t / (np.abs(t) + 1e-8)
+            steep = np.maximum(np.abs(f(gr + dgn) - f(gr)), np.abs(f(gr - dgn) - f(gr))) > tol * np.abs(wref).max()
+            bad = d > tol * np.abs(wref).max()
+            ex = bad & steep & (np.abs(gnew - gr) <= dgn)
+            steep_exempt += int(ex.sum()); hard += int((bad & ~ex).sum())
         wn += n
         off += n
     le, ae = max_rel(l0.cpu().numpy(), g["logits0"]), max_rel(l1.cpu().numpy(), g["logits1"])
@@ -247,6 +282,17 @@ def parity_check(precision):
                                           "lora_gradients": bool(gerr <= tol),
                                           "all": bool(mask and le <= tol and ae <= tol and gerr <= tol)}}
     eng.close()
+    if strict:
+        ltol, gtol = 1e-5, 1e-4
+        out["tolerances"] = {"logits": ltol, "adapted_logits": 1e-4, "gradients": gtol, "lora_weights_elementwise": tol}
+        out["lora_weights_elements_exempt_eps_steep"] = steep_exempt
+        out["lora_weights_elements_beyond_tolerance_not_exempt"] = hard
+        ok_w = hard == 0 and steep_exempt <= 16 * len(names)
+        out["meets_north_star_tolerance"] = {"selection_mask": mask, "logits": bool(le <= ltol and ae <= 1e-4), "lora_gradients": bool(gerr <= gtol),
+                                             "lora_weights": bool(ok_w), "all": bool(mask and le <= ltol and ae <= 1e-4 and gerr <= gtol and ok_w)}
+        out["note"] = ("test-only fp32 build, never timed: shows that the launch sequences and the shared LayerNorm / head / loss / optimizer kernels "
+                       "carry no systematic defect below the 16-bit builds' operand noise; weights element-wise 1e-3 except elements inside the "
+                       "eps-steep region of AdamW's first step whose own gradient agrees to 1e-5 of the tensor's max (count given)")
     return out
 
 
@@ -256,6 +302,37 @@ def parse_targets(spec):
     if spec == "qkvo":
         return ("q_proj", "k_proj", "v_proj", "out_proj")
     return tuple(t.strip() for t in spec.split(",") if t.strip())
+
+
+class StubPipeline:
+    """Host-only stand-in for ttl_amd.driver.EpisodePipeline (--stub-pipeline, CPU tests of the N-rank control flow): an image
+    takes TTL_BENCH_STUB_MS of sleep (x the factor of TTL_BENCH_STUB_SLOW='rank:factor' on that rank); the accuracy accumulator
+    counts label % 2 == 0 as a top-1 hit and every image as a top-5 hit."""
+
+    def __init__(self, rank):
+        import torch
+        self.ms = float(os.environ.get("TTL_BENCH_STUB_MS", "2.0"))
+        slow = os.environ.get("TTL_BENCH_STUB_SLOW", "")
+        if slow and int(slow.split(":")[0]) == rank:
+            self.ms *= float(slow.split(":")[1])
+        self.acc = torch.zeros(3, dtype=torch.int64)
+        self.use_graph, self.slots = False, []
+
+    def submit(self, views, target=None, **kw):
+        time.sleep(self.ms * 1e-3)
+        self.acc += __import__("torch").tensor([int(int(target[0]) % 2 == 0), 1, 1], dtype=self.acc.dtype)
+
+    def synchronize(self):
+        pass
+
+    def totals(self):
+        return self.acc.clone()
+
+    def reset_totals(self):
+        self.acc.zero_()
+
+    def close(self):
+        pass
 
 
 def lib_identity(precision):
@@ -298,14 +375,19 @@ def main():
 
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
-    if not a.same_device and torch.cuda.device_count() < world:     # (device_count does not initialise the GPU)
-        raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} devices are visible")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    if a.same_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    stub = a.stub_pipeline
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not a.same_device and torch.cuda.device_count() < world:     # (device_count does not initialise the GPU)
+            raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} devices are visible")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+        if a.same_device:
+            local = 0
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    gpu_sync = (lambda: None) if stub else torch.cuda.synchronize
     if world > 1:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -325,7 +407,7 @@ def main():
     targets = parse_targets(a.lora_targets)
     cfg = get_config(a.arch).replace(rank=a.rank, lora_targets=targets)
     lora = synth.lora_init(cfg, 0)
-    weights = synth.vision_weights(cfg, 0)
+    weights = None if stub else synth.vision_weights(cfg, 0)
     names = trainable_names(cfg)
     tfeat = torch.from_numpy(synth.text_features(a.classes, cfg.embed))
     # synthetic inputs of the workload's shape, already resident in HBM (data: synthetic).  Item i of the global stream
@@ -333,13 +415,13 @@ def main():
     # ALL pool batches whatever the world size; i % pool would hand a rank ONE batch whenever world is a multiple of pool —
     # an Infinity-Cache-resident input the 1-GPU run does not have) with label (7 * batch) % classes: what an item is depends
     # on i only, so the accuracy accumulator of N ranks x K steps equals 1 rank x N*K steps (tests/test_gpu_bench_contract.py).
-    pool = [torch.from_numpy(synth.views(cfg, a.views, 1000 + j)).to(dev) for j in range(a.pool)]
+    pool = [torch.zeros(1) if stub else torch.from_numpy(synth.views(cfg, a.views, 1000 + j)).to(dev) for j in range(a.pool)]
     labels = [torch.tensor([(7 * j) % a.classes], device=dev) for j in range(a.pool)]
     item = lambda i: ((i * 2654435761) >> 16) % a.pool
 
     # the legs: BOTH operand builds under one protocol (auto), or the one asked for.  The conforming build comes first.
     legs = ["fp16", "bf16"] if a.precision == "auto" else [a.precision]
-    ident = {p: lib_identity(p) for p in legs}
+    ident = {p: ({"lib_path": "stub (--stub-pipeline)", "lib_sha256_16": None} if stub else lib_identity(p)) for p in legs}
 
     # ---- untimed parity of every leg against the reference-generated fixture (rank 0; decides the headline in auto mode)
     parity = {}
@@ -349,6 +431,10 @@ def main():
                 parity[p] = parity_check(p)
             except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
                 parity[p] = {"error": f"{type(e).__name__}: {e}"}
+        try:                            # the test-only fp32 build on the same fixture (never timed)
+            parity["strict"] = parity_check("strict")
+        except Exception as e:
+            parity["strict"] = {"error": f"{type(e).__name__}: {e}"}
 
     def conforms(p):
         m = parity.get(p, {}).get("meets_north_star_tolerance")
@@ -358,11 +444,11 @@ def main():
         """-> seconds until THIS rank's streams were drained (before the barrier the other ranks join)"""
         t = time.perf_counter()
         pipe.synchronize()
-        torch.cuda.synchronize()
+        gpu_sync()
         t_local = time.perf_counter() - t
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            gpu_sync()
         return t_local
 
     def block(pipe, n_items):
@@ -377,6 +463,8 @@ def main():
         return float(shard.max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()), t_enq, t_local
 
     def make_pipe(precision, use_graph):
+        if stub:
+            return StubPipeline(rank)
         return EpisodePipeline(cfg, weights, names, lora, tfeat, 100.0, dev, n_streams=a.streams, max_views=a.views,
                                precision=precision, use_graph=use_graph)
 
@@ -509,24 +597,30 @@ def main():
         return roof, executed
 
     roofs, executed = {}, None
-    if rank == 0:
+    if rank == 0 and not stub:
         for p in legs:
             roofs[p], ex = roofline_of(pipes[p])
             executed = ex if executed is None else executed
         # HBM-side traffic of the same launches: PMC passes cannot run inside this process, so the figure is STATIC: read
         # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this command (tools/pmc_traffic.py)
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
-        if cand and a.arch == "ViT-B/16" and a.views == 64 and a.classes == 200 and a.rank == 16 and a.updates == 1 and a.lora_targets == "qv":
-            try:
-                tj = json.load(open(cand[-1]))
-                for p in legs:
+        if a.arch == "ViT-B/16" and a.views == 64 and a.classes == 200 and a.rank == 16 and a.updates == 1 and a.lora_targets == "qv":
+            for p in legs:
+                # the newest file measured on THIS leg's build (r05+: r*_gemm_traffic_<dtype>.json); failing that, the newest of the
+                # earlier rounds' files — all of them measured on the bf16 build, and labelled so
+                own = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_gemm_traffic_{p}.json")))
+                old = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[1-4]_gemm_traffic.json")))
+                src = own[-1] if own else (old[-1] if old else None)
+                if not src:
+                    continue
+                try:
+                    tj = json.load(open(src))
                     roofs[p]["traffic"] = tj["traffic_bytes_per_launch"]
-                    roofs[p]["traffic_source"] = "profiles/" + os.path.basename(cand[-1])
-                    roofs[p]["traffic_regime"] = "static (bf16 build; the fp16 build moves the same bytes): " + tj.get(
+                    roofs[p]["traffic_source"] = "profiles/" + os.path.basename(src)
+                    roofs[p]["traffic_regime"] = ("static, measured on this leg's build: " if own else "static, measured on the bf16 build (no PMC pass of this build is committed): ") + tj.get(
                         "regime", "rocprofv3 --pmc, streams=1, separate FETCH_SIZE / WRITE_SIZE passes")
-            except Exception:
-                pass
+                except Exception:
+                    pass
     for p in legs:
         pipes[p].close()
 
@@ -584,7 +678,21 @@ def main():
             out["per_rank_value"] = n["per_rank_value"]
             out["rank_balance"] = n["rank_balance"]
         if head in parity:
-            out["parity"] = parity[head]
+            out["parity"] = dict(parity[head])
+            if "strict" in parity:
+                out["parity"]["strict"] = parity["strict"]
+        # stable per-build keys whatever the headline rule picks (round-4 advisor): compare rounds on these
+        for p in legs:
+            out["value_" + p] = numbers[p]["value"]
+        if not conforms(head) and parity:
+            out["headline_conforms"] = False
+            out["headline_warning"] = ("NO timed build met the selection-mask + logit tolerance on the parity fixture in this run: `value` is the "
+                                       f"{head} build's rate, unqualified; see `parity`")
+        elif parity:
+            out["headline_conforms"] = True
+        if stub:
+            out["stub"] = True
+            out["metric"] = "STUB (--stub-pipeline): control flow of the N-rank run only, not a measurement"
         out["legs"] = {}
         for p in legs:
             leg = dict(numbers[p])
@@ -604,6 +712,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if bad_balance and a.strict_balance:
+        if rank == 0 and os.environ.get("TTL_BENCH_STATUS_FILE"):
+            with open(os.environ["TTL_BENCH_STATUS_FILE"], "w") as f:
+                f.write("3")
         raise SystemExit(3)
 
 

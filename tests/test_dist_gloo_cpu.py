@@ -212,3 +212,48 @@ def test_visible_device_lists_compose_and_unresolvable_ones_do_not_pin(tmp_path)
 def test_gather_is_identity_for_one_rank():
     t = torch.tensor([1.5, 2.5], dtype=torch.float64)
     assert torch.equal(ImageShard(0, 1).gather(t), t.reshape(1, 2))
+
+
+def _run_bench_stub(extra, env=None, n=8):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, TTL_BENCH_STUB_MS="3")
+    e.update(env or {})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):       # bench.py must start its own ranks
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--stub-pipeline", "--steps", "12", "--warmup", "2",
+                        "--repeats", "3"] + extra, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-2000:]
+
+
+def test_bench_control_flow_of_an_eight_rank_run():
+    """bench.py --gpus 8 end to end on CPU (round-4 review item 6b): the real self-spawn (torch.distributed.run started by bench.py
+    itself), the ranks_seen all-reduce, timed blocks bracketed by barriers with the max over ranks, per-rank rates gathered through
+    ImageShard, rank_balance and the ONE JSON line of rank 0 — with a host-only stand-in for the episode pipeline (--stub-pipeline:
+    a sleep per image) and gloo.  Only the headline leg runs by default when N > 1."""
+    rc, j, err = _run_bench_stub([])
+    assert rc == 0 and j is not None, err
+    assert j["stub"] is True and j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["scaling"] == "weak"
+    assert j["protocol"]["legs"] == ["fp16"] and list(j["legs"]) == ["fp16"]           # N > 1: the headline build alone
+    assert len(j["per_rank_value"]) == 8 and j["rank_balance"]["ok"] is True
+    assert j["config"]["backend"] == "gloo" and "image-sharded x8" in j["config"]["parallelism"]
+    # 8 ranks x 12 steps of 3 ms: whole-job rate = 8 x one rank's; every image of the last timed block is in the accumulator
+    assert 0.5 * 8 / 3e-3 < j["value"] <= 8 / 3e-3
+    assert abs(j["value"] - sum(j["per_rank_value"])) < 0.25 * j["value"]
+    assert j["accuracy_accumulator"]["images"] == 8 * 12
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+
+
+def test_bench_flags_a_slow_rank_and_strict_balance_exits_3():
+    """One rank 20 % slower than the others: rank_balance.ok is false in the line; with --strict-balance bench.py exits 3 (the
+    code travels from rank 0 through the self-spawn), without it the run still succeeds and reports."""
+    slow = {"TTL_BENCH_STUB_SLOW": "5:1.2"}
+    rc, j, err = _run_bench_stub([], slow)
+    assert rc == 0 and j["rank_balance"]["ok"] is False and j["rank_balance"]["slowest_over_median"] < 0.9, (rc, j and j["rank_balance"], err)
+    assert min(range(8), key=lambda r: j["per_rank_value"][r]) == 5
+    rc, j, err = _run_bench_stub(["--strict-balance"], slow)
+    assert rc == 3 and j["rank_balance"]["ok"] is False, (rc, err)

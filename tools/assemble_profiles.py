@@ -1,5 +1,6 @@
 """Turn the scratch output of tools/collect_profiles.sh (gpurun_out/<run>/) into the tracked evidence files profiles/<tag>_*:
-    python tools/assemble_profiles.py gpurun_out/r02b r02
+    python tools/assemble_profiles.py gpurun_out/r05_fp16 r05 [fp16]
+(third argument: a suffix naming the operand build the files were measured on -> profiles/<tag>_<name>_<suffix>.<ext>)
 bench line (pretty-printed), rocprofv3 kernel stats for 3 streams / 1 stream, per-shape GEMM durations, the other
 configurations' bench lines in short form, and achieved GB/s of the HBM-bound kernels (kernel-trace durations / algorithmic bytes).
 """
@@ -35,19 +36,28 @@ def short(d):
             "reference_flops_x_rate_over_peak__counts_work_this_build_skips": d.get("whole_path_frac_of_bf16_peak")}
 
 
-def main(src, tag):
+def main(src, tag, suffix=""):
     out = "profiles"
     os.makedirs(out, exist_ok=True)
+    sfx = ("_" + suffix) if suffix else ""
+    _open, _copy = open, shutil.copy
+
+    def named(path):          # profiles/r05_bench.json -> profiles/r05_bench_fp16.json
+        if not sfx or not path.startswith(out + "/"):
+            return path
+        root, ext = os.path.splitext(path)
+        return root + sfx + ext
+    open_w = lambda path, mode="w": _open(named(path), mode)
     b = last_json(f"{src}/bench.json")
     if b:
-        json.dump(b, open(f"{out}/{tag}_bench.json", "w"), indent=1)
+        json.dump(b, open_w(f"{out}/{tag}_bench.json"), indent=1)
     # ONE kernel-stats file: rocprofv3 serialises kernels, so the regime is "kernel alone on the chip" whatever --streams was
     for sub, name in (("prof1/p1_kernel_stats.csv", "bench_kernel_stats_serialized.csv"),):
         cand = [os.path.join(dp, f) for dp, _, fs in os.walk(f"{src}/{sub.split('/')[0]}") for f in fs if f.endswith("kernel_stats.csv")]
         if cand:
-            shutil.copy(cand[0], f"{out}/{tag}_{name}")
+            shutil.copy(cand[0], named(f"{out}/{tag}_{name}"))
     if os.path.exists(f"{src}/prof1_gemm_shapes.txt"):
-        shutil.copy(f"{src}/prof1_gemm_shapes.txt", f"{out}/{tag}_gemm_shapes_serialized.txt")
+        shutil.copy(f"{src}/prof1_gemm_shapes.txt", named(f"{out}/{tag}_gemm_shapes_serialized.txt"))
     other = {}
     for key, f in (("streams1", "bench_streams1.json"), ("adapters_q_k_v_out", "bench_qkvo.json"), ("plain_enqueues_no_graph", "bench_graph0.json"),
                    ("k1000", "bench_k1000.json"), ("vit_l14", "bench_l14.json"),
@@ -68,10 +78,10 @@ def main(src, tag):
             sweep[f"streams{n}"]["hip_graph"] = d["protocol"]["hip_graph"]
     if sweep:
         other["streams_sweep_bf16"] = sweep
-    json.dump(other, open(f"{out}/{tag}_other_configs.json", "w"), indent=1)
+    json.dump(other, open_w(f"{out}/{tag}_other_configs.json"), indent=1)
     for f in ("pmc_summary.txt", "pmc_memory_path.txt", "gemm_traffic.json", "class_cost_in_flight.txt", "parity_per_fixture.txt"):
         if os.path.exists(f"{src}/{f}"):
-            shutil.copy(f"{src}/{f}", f"{out}/{tag}_{f}")
+            shutil.copy(f"{src}/{f}", named(f"{out}/{tag}_{f}"))
     # HBM-bound kernels: per-launch durations from the 1-stream kernel trace
     trace = [os.path.join(dp, f) for dp, _, fs in os.walk(f"{src}/prof1") for f in fs if f.endswith("kernel_trace.csv")]
     if trace:
@@ -104,9 +114,9 @@ def main(src, tag):
                                              "algorithmic_bytes": nb, "median_us": us, "achieved_GBps": round(nb / us / 1e3, 1),
                                              "note": "byte work bound by the integer tap arithmetic (bit-exact Pillow fixed point), not by HBM"}
         json.dump({"source": f"rocprofv3 --kernel-trace of `bench.py --streams 1` (profiles/{tag}_bench_kernel_stats_serialized.csv), tools/views_bench.py",
-                   "kernels": k}, open(f"{out}/{tag}_hbm_kernels.json", "w"), indent=1)
+                   "kernels": k}, open_w(f"{out}/{tag}_hbm_kernels.json"), indent=1)
     print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag + "_")))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

@@ -1,8 +1,11 @@
 #!/bin/bash
 # PMC evidence of a round (separate passes: the MI355X guide's HBM/rocprofv3 section; never combined with trace domains):
-#   bash tools/collect_pmc.sh r02      -> gpurun_out/r02/pmc_*/ ; summary + traffic json under gpurun_out/r02/
-R=${1:-r04}
-cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$R; mkdir -p $O
+#   bash tools/collect_pmc.sh r05 [fp16|bf16]   -> gpurun_out/r05_fp16/pmc_*/ ; summary + traffic json beside them
+# (second argument: the operand build tools/quick_bench.py runs, through TTL_PRECISION; default fp16 = the headline build)
+R=${1:-r05}
+P=${2:-fp16}
+export TTL_PRECISION=$P
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${R}_$P; mkdir -p $O
 # every pass under its own timeout: a counter set the hardware cannot collect makes rocprofv3 abort and then hang
 pass() { name=$1; shift; timeout 200 rocprofv3 --pmc "$@" -d $O/pmc_$name -o $name --output-format csv -- python3 tools/quick_bench.py > $O/pmc_$name.log 2>&1; echo "pass $name rc=$?"; }
 pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE

@@ -1,4 +1,5 @@
-"""Quick timing of the B/16 episode + per-class profile (run on the GPU box)."""
+"""Quick timing of the B/16 episode + per-class profile (run on the GPU box).
+    python tools/quick_bench.py [arch views classes]      TTL_PRECISION=fp16|bf16 picks the operand build (default fp16, the headline)"""
 import sys, os, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,9 @@ cfg = get_config(arch)
 t0 = time.time()
 W = synth.vision_weights(cfg, 0)
 print("weights gen", time.time() - t0)
-eng = TTLEngine(cfg, N, K, "cuda:0")
+PREC = os.environ.get("TTL_PRECISION", "fp16")
+print("operand build:", PREC)
+eng = TTLEngine(cfg, N, K, "cuda:0", precision=PREC)
 eng.load_weights(W)
 eng.set_text_features(torch.from_numpy(synth.text_features(K, cfg.embed)), 100.0)
 lora = synth.lora_init(cfg, 0)

@@ -11,6 +11,8 @@ from ttl_amd.custom_clip import build_text_mode_engine
 from ttl_amd.driver import EpisodePipeline
 
 arch = "ViT-B/16"
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp16"       # operand build (fp16 = the headline build)
+print("operand build:", PREC)
 vcfg, tcfg = get_config(arch), get_text_config(arch)
 Wv, Wt = synth.vision_weights(vcfg, 0), synth.text_weights(tcfg, 0)
 lora = synth.lora_init(tcfg, 0, tower="text_model")
@@ -21,8 +23,8 @@ views = [torch.from_numpy(synth.views(vcfg, 64, 1000 + j)).to(dev) for j in rang
 for K in (200, 1000):
     ids = synth.token_ids(K, tcfg, 3)
     for streams in (1, 2, 3):
-        fac = lambda: build_text_mode_engine(vcfg, tcfg, Wv, Wt, ids, 100.0, dev, 64, K)
-        pipe = EpisodePipeline(vcfg, None, names, lora, None, 100.0, dev, n_streams=streams, max_views=64, engine_factory=fac, n_classes=K)
+        fac = lambda: build_text_mode_engine(vcfg, tcfg, Wv, Wt, ids, 100.0, dev, 64, K, PREC)
+        pipe = EpisodePipeline(vcfg, None, names, lora, None, 100.0, dev, n_streams=streams, max_views=64, precision=PREC, engine_factory=fac, n_classes=K)
         for i in range(6):
             pipe.submit(views[i % 4], n_updates=1)
         pipe.synchronize()

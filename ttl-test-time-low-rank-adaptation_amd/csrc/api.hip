@@ -1205,6 +1205,10 @@ int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, vo
 // + dZ, which also clears found_inf) + 3 head backward + 1 optimizer (GradScaler decision + AdamW), then 2 head launches of the
 // adapted prediction writing into the caller's buffer and, with a target, 1 hit-count launch.
 static int episode_tail(ttl_ctx* c, const ttl_episode_args* a, const float* logits1, hipStream_t s) {
+    // found_inf describes the gradients between a backward and its optimizer step; the fused optimizer launch cannot clear it (every
+    // block of that launch reads it), so an episode whose LAST update overflowed would leave it set for a step-wise
+    // ttl_scaler_unscale + ttl_optimizer_step that follows without a backward in between (round-4 advisor)
+    if (a->n_updates > 0) HIP_TRY(hipMemsetAsync(c->sc.i + SC_FOUND_INF, 0, sizeof(int), s));
     if (!a->target && !a->hits_out) return 0;
     if (!a->target || !a->hits_out) return fail(TTL_EINVAL, "target and hits_out go together");
     Prof p(c, 5, s);

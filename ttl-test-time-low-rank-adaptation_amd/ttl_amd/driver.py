@@ -11,6 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def dist_env():
     """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
@@ -447,7 +449,9 @@ class EpisodePipeline:
         views.record_stream(sl["stream"])          # the caching allocator must not recycle it under the slot's stream
         hits = sl["acc"] if target is not None else None
         if target is not None:
-            assert target.dtype == torch.int64 and target.is_cuda
+            if not (torch.is_tensor(target) and target.is_cuda and target.dtype == torch.int64 and target.numel() >= 1 and target.is_contiguous()):
+                raise _lib.TtlError("target must be a contiguous device int64 tensor (topk_hits_kernel reads 8 bytes per label); "
+                                    "coerce with .to(device, dtype=torch.int64)")
             target.record_stream(sl["stream"])
         with torch.cuda.stream(sl["stream"]):
             if self.use_graph:

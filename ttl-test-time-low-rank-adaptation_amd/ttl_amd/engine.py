@@ -278,8 +278,9 @@ class TTLEngine:
         if (target is None) != (hits is None):
             raise _lib.TtlError("target and hits go together")
         if target is not None:
-            assert target.is_cuda and target.dtype == torch.int64 and target.numel() >= 1 and target.is_contiguous()
-            assert hits.is_cuda and hits.dtype == torch.int64 and hits.numel() >= 3 and hits.is_contiguous()
+            for t, n, what in ((target, 1, "target"), (hits, 3, "hits")):       # raw int64 pointers cross the C ABI: a real check, not an assert
+                if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 and t.numel() >= n and t.is_contiguous()):
+                    raise _lib.TtlError(f"{what} must be a contiguous device int64 tensor with at least {n} element(s)")
             a.target, a.hits_out = target.data_ptr(), hits.data_ptr()
 
     def episode_graph(self, x_buf, snapshot, m, v, logits1_buf, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH,

@@ -103,7 +103,7 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
             images = images.to(dev, non_blocking=True)
             if images.dim() == 5:
                 images = images.squeeze(0)
-        tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev)
+        tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev, dtype=torch.int64)     # the device-side hit count reads an int64 label
         pipe.submit(images, target=tgt, **kw)
         if progress is not None:
             progress.note(i, lambda: (pipe.totals() + acc0).tolist())
