@@ -115,6 +115,28 @@ def test_big_gemm_epilogues_issue_the_stores_the_counted_waits_allow_for():
     assert "gemm_big_kernel<5,3,2>: 20 store" in r.stdout
 
 
+def test_no_load_lands_in_the_result_registers_of_an_mfma_in_flight():
+    """tools/scan_mfma_srcc_reuse.py on the ISA of both product builds (round-4 review item 5): no DS read / VMEM load may target
+    the vDst block of an MFMA issued <= 4 instructions earlier whose result nothing has consumed yet.  (Loads into a RETIRED SrcC
+    block — the pattern round 4 suspected — are what hipcc's allocator emits hundreds of times in the shipped, bitwise-repeatable
+    GEMM main loops; the scan counts them and says so.)"""
+    import re, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_mfma_srcc_reuse.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "(must be 0): 0" in r.stdout
+    for build in ("bf16", "fp16"):
+        assert re.search(rf"{build}\s+gemm_big.hip\s+\d{{4}} MFMA instructions", r.stdout), r.stdout[-1500:]    # the scan really saw the kernels
+
+
+def test_the_three_builds_export_the_same_abi():
+    """libttl_hip.so, libttl_hip_fp16.so and the test-only libttl_hip_strict.so: every symbol include/ttl_hip.h declares, and
+    each says which operand type it was built for."""
+    for prec, dt in _lib.OPERAND_DTYPE.items():
+        lib = _lib.load(prec)
+        assert lib.ttl_operand_dtype().decode() == dt
+        assert not [s for s in _lib.header_symbols() if not hasattr(lib, s)]
+
+
 def test_degenerate_configs_are_refused_not_crashed():
     """Config validation runs before anything touches a device: an all-zero ttl_config (heads == 0 used to divide by zero —
     found by the ASan host test) and other degenerate fields come back as TTL_EINVAL with a message."""
