@@ -196,6 +196,38 @@ int ttl_lora_reset(float* params, const float* snapshot, float* exp_avg, float* 
  *   LoRA backward, AdamW] -> logits of view 0 with the adapted weights.
  *   snapshot/exp_avg/exp_avg_sq: flat fp32 buffers shaped like the bound params.
  *   logits0_out [N,K] (first forward) may be NULL; logits1_out [1,K]. */
+/* ---- PLPD filter of DeYO (--filter_plpd 1, deyo.py:115-151) on the device ----
+ * x' = destroy(x[filter_ids_1]) (deyo.py:116-134), a second forward of x' (deyo.py:135), and
+ * keep = softmax(z[ids1])[argmax] - softmax(z')[same class] > plpd_threshold (deyo.py:137-146) folded into the loss launch.
+ * The permutations are drawn by the HOST exactly as the reference draws them — torch.argsort(torch.rand(B, patch_len^2), dim=-1)
+ * per update for 'patch' (B = n_candidates rows), torch.randperm(S*S) per update for 'pixel', on torch's CPU generator — and
+ * handed over as device int32 arrays; 'occ' needs none. */
+enum { TTL_PLPD_OCC = 0, TTL_PLPD_PATCH = 1, TTL_PLPD_PIXEL = 2 };
+typedef struct ttl_plpd_args {
+    int aug_type;                                  /* TTL_PLPD_* (--aug_type) */
+    float threshold;                               /* --plpd_threshold */
+    int patch_len;                                 /* --patch_len ('patch') */
+    int occlusion_size, row_start, column_start;   /* --occlusion_size / --row_start / --column_start ('occ') */
+    const int* perm;     /* device int32; 'patch': [n_updates][n_candidates][patch_len^2], 'pixel': [n_updates][size*size], 'occ': NULL */
+    int n_candidates;    /* views the FIRST selection stage yields — the row count of the reference's torch.rand(B, P): int(N*rho) in
+                          * top-rho mode, N in threshold mode (H <= ln 1000 always holds for K <= 1000 classes).  The device-side count
+                          * guards every kernel; the second forward runs on n_candidates rows. */
+    ttl_ctx* aux;        /* image mode: a SECOND context of the same model (ttl_ctx_create_shared is fine) holding the same class
+                          * embeddings and bound (ttl_bind_lora) to the SAME parameter buffer: the PLPD forward must not overwrite the
+                          * activations the pending backward needs.  Text mode (ttl_episode_text): NULL, the image context serves. */
+} ttl_plpd_args;
+/* The destroyed views on their own (step-wise path, tests): x device fp32 [n_views,3,size,size]; idx device int64 (the first-stage
+ * selection list), n_sel device int32 (its length; rows b >= *n_sel of `out` are left untouched), n_max = rows the launch is sized
+ * for; p->perm = the permutations of ONE update; out device fp32 [n_max,3,size,size]; workspace: device scratch of at least
+ * ttl_plpd_views_workspace_bytes() bytes (may be NULL when that is 0). */
+size_t ttl_plpd_views_workspace_bytes(int n_max, int size, const ttl_plpd_args* p);
+int ttl_plpd_views(const float* x, int size, const int64_t* idx, const int* n_sel, int n_max, const ttl_plpd_args* p, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* keep_out device uint8 [N]: 1 for the first-stage views whose PLPD exceeds the threshold, 0 elsewhere (the `keep` argument of
+ * ttl_entropy_select_loss); logits [N,K], logits_prime [n_max,K] (row b belongs to view idx[b]); plpd_out fp32 [n_max] or NULL. */
+int ttl_plpd_keep(const float* logits, const float* logits_prime, const int64_t* idx, const int* n_sel, int n_max, int N, int K,
+                  float threshold, unsigned char* keep_out, float* plpd_out, void* stream);
+
 typedef struct ttl_episode_args {
     const float* x;      /* [N,3,S,S] */
     int n_views;
@@ -215,6 +247,10 @@ typedef struct ttl_episode_args {
      * (top-min(5,K)), 1}.  Both NULL: no counting.  Ties rank the lower class index first; a label outside [0, K) never hits. */
     const int64_t* target;
     int64_t* hits_out;
+    /* --filter_plpd 1 inside the fused episode (DeYO objective only); NULL = no PLPD stage.  Per update: first-stage selection ->
+     * destroyed views -> second forward -> keep mask -> loss over the survivors; "idx" / "n_selected" of ttl_debug_copy then hold
+     * the SECOND-stage list (filter_ids_1[filter_ids_2]). */
+    const ttl_plpd_args* plpd;
 } ttl_episode_args;
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);
 

@@ -16,7 +16,7 @@ def test_library_is_built_in_tree():
         _lib.load("fp8")
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "strict"])
 def test_exports_match_header(precision):
     lib = _lib.load(precision)
     declared = _lib.header_symbols()
@@ -25,7 +25,7 @@ def test_exports_match_header(precision):
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.ttl_version().startswith(b"ttl_hip")
-    assert lib.ttl_operand_dtype() == precision.encode()
+    assert lib.ttl_operand_dtype() == _lib.OPERAND_DTYPE[precision].encode()
 
 
 def test_config_validation_without_gpu():
@@ -85,7 +85,7 @@ def test_struct_layouts_match_the_header_and_the_documented_stub(tmp_path):
 
     gcc = shutil.which("gcc")
     assert gcc, "gcc is part of the image"
-    for name, ct in (("ttl_config", _lib.ttl_config), ("ttl_episode_args", _lib.ttl_episode_args)):
+    for name, ct in (("ttl_config", _lib.ttl_config), ("ttl_episode_args", _lib.ttl_episode_args), ("ttl_plpd_args", _lib.ttl_plpd_args)):
         fields = c_fields(name)
         assert fields == [f[0] for f in ct._fields_], (name, fields)
         src = tmp_path / (name + ".c")

@@ -120,6 +120,11 @@ struct ttl_ctx {
     float* wg_partial;
     float* gemm_ws; size_t gemm_ws_bytes;
     float* loss_scratch; long long* idx_buf; int* n_buf; float* loss_buf; float* H_buf;
+    // PLPD filter (deyo.py:115-151): keep mask + plpd values of the saving context; destroyed views + scratch of the context that runs
+    // the second forward (allocated on first use); text mode: normalised features of the destroyed views and their logits
+    unsigned char* keep_buf = nullptr; float* plpd_val = nullptr;
+    float* plpd_x = nullptr; float* plpd_ws = nullptr; size_t plpd_ws_floats = 0;
+    float *plpd_tf = nullptr, *plpd_tfT = nullptr, *plpd_lkn = nullptr, *plpd_lnk = nullptr;
     // GradScaler state (device) and policy (host): ttl.py:222, deyo.py:186-188
     ScalerState sc{nullptr, nullptr};
     int sc_dynamic = 0; float sc_growth = 2.f, sc_backoff = 0.5f; int sc_interval = 2000;
@@ -383,6 +388,7 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
     const size_t nmax = N > (size_t)k->max_classes ? N : (size_t)k->max_classes;
     ALLOC(c->loss_scratch, 7 * nmax + 16, true);
     ALLOC(c->idx_buf, nmax, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, nmax, true);
+    ALLOC(c->keep_buf, nmax, true); ALLOC(c->plpd_val, nmax, true);
     ALLOC(c->sc.f, SC_NF, true); ALLOC(c->sc.i, SC_NI, true);
     {   // fp16-operand build: dynamic loss scaling from 2^10 like the reference's GradScaler(init_scale=1000) (ttl.py:222);
         // bf16 needs no loss scale (scale 1, fixed) but keeps the whole-step skip on non-finite gradients
@@ -1200,6 +1206,61 @@ int ttl_lora_reset(float* p, const float* snap, float* m, float* v, size_t n, vo
     return 0;
 }
 
+// ------------------------------------------------------------------------------ PLPD filter (deyo.py:115-151)
+static int plpd_check(const ttl_plpd_args* p, int n_views, int S) {
+    if (p->aug_type != TTL_PLPD_OCC && p->aug_type != TTL_PLPD_PATCH && p->aug_type != TTL_PLPD_PIXEL)
+        return fail(TTL_EINVAL, "unknown aug_type %d", p->aug_type);
+    if (p->n_candidates < 1 || p->n_candidates > n_views) return fail(TTL_EINVAL, "n_candidates %d outside [1,%d]", p->n_candidates, n_views);
+    if (p->aug_type != TTL_PLPD_OCC && !p->perm) return fail(TTL_EINVAL, "aug_type 'patch' / 'pixel' needs the host-drawn permutations");
+    if (p->aug_type == TTL_PLPD_PATCH && (p->patch_len < 1 || p->patch_len > S)) return fail(TTL_EINVAL, "patch_len %d outside [1,%d]", p->patch_len, S);
+    if (p->aug_type == TTL_PLPD_OCC && (p->occlusion_size < 1 || p->row_start < 0 || p->column_start < 0 ||
+                                        p->row_start + p->occlusion_size > S || p->column_start + p->occlusion_size > S))
+        return fail(TTL_EINVAL, "occlusion window [%d+%d, %d+%d] outside the %d x %d view", p->row_start, p->occlusion_size, p->column_start,
+                    p->occlusion_size, S, S);
+    return 0;
+}
+static PlpdArgs plpd_launch_args(const ttl_plpd_args* p, int update, int S) {
+    PlpdArgs a = {p->aug_type, p->patch_len, p->occlusion_size, p->row_start, p->column_start, p->perm};
+    if (a.perm) a.perm += (size_t)update * (p->aug_type == TTL_PLPD_PATCH ? (size_t)p->n_candidates * p->patch_len * p->patch_len : (size_t)S * S);
+    return a;
+}
+// the context `f` that runs the second forward owns the destroyed views (allocated on first use: never inside a stream capture,
+// ttl_episode_capture runs the episode eagerly first)
+static int plpd_buffers(ttl_ctx* f, const ttl_plpd_args* p) {
+    ttl_ctx* c = f;
+    if (!c->plpd_x) ALLOC(c->plpd_x, (size_t)c->c.max_views * 3 * c->S * c->S, false);
+    const size_t need = plpd_views_workspace_floats(c->c.max_views, c->S, p->aug_type, p->patch_len);
+    if (need > c->plpd_ws_floats) { ALLOC(c->plpd_ws, need, false); c->plpd_ws_floats = need; }
+    return 0;
+}
+
+size_t ttl_plpd_views_workspace_bytes(int n_max, int size, const ttl_plpd_args* p) {
+    if (!p || n_max < 1 || size < 1) return 0;
+    return plpd_views_workspace_floats(n_max, size, p->aug_type, p->patch_len) * sizeof(float);
+}
+
+int ttl_plpd_views(const float* x, int size, const int64_t* idx, const int* n_sel, int n_max, const ttl_plpd_args* p, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !idx || !n_sel || !p || !out) return fail(TTL_EINVAL, "null argument");
+    if (n_max < 1 || size < 1) return fail(TTL_EINVAL, "bad shape");
+    ttl_plpd_args q = *p;
+    q.n_candidates = n_max;
+    int rc = plpd_check(&q, n_max, size);
+    if (rc) return rc;
+    const size_t need = ttl_plpd_views_workspace_bytes(n_max, size, p);
+    if (need && (!workspace || workspace_bytes < need)) return fail(TTL_EINVAL, "workspace smaller than ttl_plpd_views_workspace_bytes()");
+    HIP_TRY(launch_plpd_views(x, (const long long*)idx, n_sel, n_max, size, plpd_launch_args(&q, 0, size), out, (float*)workspace, (hipStream_t)stream));
+    return 0;
+}
+
+int ttl_plpd_keep(const float* logits, const float* logits_prime, const int64_t* idx, const int* n_sel, int n_max, int N, int K,
+                  float threshold, unsigned char* keep_out, float* plpd_out, void* stream) {
+    if (!logits || !logits_prime || !idx || !n_sel || !keep_out) return fail(TTL_EINVAL, "null argument");
+    if (n_max < 1 || n_max > N || K < 1) return fail(TTL_EINVAL, "bad shape");
+    HIP_TRY(launch_plpd_keep(logits, logits_prime, (const long long*)idx, n_sel, n_max, N, K, threshold, keep_out, plpd_out, (hipStream_t)stream));
+    return 0;
+}
+
 // Launches of an episode outside the towers (round 4): 1 reset (LoRA, Adam moments, scaler step counters),
 // per update 2 head forward (LayerNorm of the pooled rows + projection; norm + logits) + 2 loss (row statistics; selection + loss
 // + dZ, which also clears found_inf) + 3 head backward + 1 optimizer (GradScaler decision + AdamW), then 2 head launches of the
@@ -1223,6 +1284,18 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    const ttl_plpd_args* pl = a->plpd;
+    if (pl) {      // --filter_plpd 1: everything is checked before the first launch
+        if (a->objective != 0) return fail(TTL_EINVAL, "the PLPD filter belongs to the DeYO objective (deyo.py:115)");
+        if (a->n_views < 1 || a->n_views > c->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", a->n_views, c->c.max_views);
+        if ((rc = plpd_check(pl, a->n_views, c->S))) return rc;
+        ttl_ctx* x2 = pl->aux;
+        if (!x2 || x2 == c || x2->text) return fail(TTL_EINVAL, "plpd.aux must be a second image-tower context");
+        if (!same_model(x2->c, c->c) || x2->c.max_views < pl->n_candidates) return fail(TTL_EINVAL, "plpd.aux: another model or too few views");
+        if (x2->lora_p != c->lora_p) return fail(TTL_ESTATE, "plpd.aux must be bound (ttl_bind_lora) to the same parameter buffer");
+        if (x2->K != c->K) return fail(TTL_ESTATE, "plpd.aux holds %d class embeddings, the context %d", x2->K, c->K);
+        if ((rc = plpd_buffers(x2, pl))) return rc;
+    }
     LoraImages im;
     const bool fresh = lora_images(c, &im);     // reset and optimizer launches keep the operand-dtype LoRA images current themselves
     {
@@ -1233,11 +1306,31 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
         if ((rc = forward_impl(c, a->x, a->n_views, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr,
                                stream, fresh)))
             return rc;
+        const unsigned char* keep = nullptr;
+        if (pl) {
+            // deyo.py:102-108 first-stage selection -> :116-134 destroyed views -> :135 second forward (on the auxiliary context: the
+            // activations saved above belong to the pending backward) -> :137-146 keep mask
+            ttl_ctx* x2 = pl->aux;
+            {
+                Prof p(c, 5, s);
+                HIP_TRY(launch_entropy_loss(c->logits, a->n_views, c->K, 0, a->mode, a->rho, a->thresh, a->margin, a->reweight, 0, c->H_buf,
+                                            c->idx_buf, c->n_buf, c->loss_buf, c->dlogits, c->loss_scratch, s));
+                HIP_TRY(launch_plpd_views(a->x, c->idx_buf, c->n_buf, pl->n_candidates, c->S, plpd_launch_args(pl, u, c->S), x2->plpd_x,
+                                          x2->plpd_ws, s));
+            }
+            if ((rc = forward_impl(x2, x2->plpd_x, pl->n_candidates, 0, 0, nullptr, nullptr, stream))) return rc;
+            {
+                Prof p(c, 5, s);
+                HIP_TRY(launch_plpd_keep(c->logits, x2->logits, c->idx_buf, c->n_buf, pl->n_candidates, a->n_views, c->K, pl->threshold,
+                                         c->keep_buf, c->plpd_val, s));
+            }
+            keep = c->keep_buf;
+        }
         {
             Prof p(c, 5, s);
             HIP_TRY(launch_entropy_loss(c->logits, a->n_views, c->K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf, c->dlogits,
-                                        c->loss_scratch, s, nullptr, c->sc.i + SC_FOUND_INF));
+                                        c->loss_scratch, s, keep, c->sc.i + SC_FOUND_INF));
         }
         if ((rc = backward_impl(c, c->dlogits, a->n_views, stream, true))) return rc;
         {
@@ -1308,6 +1401,18 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     if (v->E != c->E) return fail(TTL_EINVAL, "embed dims differ (%d vs %d)", v->E, c->E);
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    const ttl_plpd_args* pl = a->plpd;
+    if (pl) {      // --filter_plpd 1 with --lora_encoder text: the destroyed views need image FEATURES only, the image context serves
+        if (a->objective != 0) return fail(TTL_EINVAL, "the PLPD filter belongs to the DeYO objective (deyo.py:115)");
+        if (a->n_views < 1 || a->n_views > v->c.max_views) return fail(TTL_EINVAL, "n_views %d outside [1,%d]", a->n_views, v->c.max_views);
+        if ((rc = plpd_check(pl, a->n_views, v->S))) return rc;
+        if ((rc = plpd_buffers(v, pl))) return rc;
+        if (!c->plpd_tf) {
+            const size_t nv = c->c.max_classes, np = c->c.max_views;      // (text context: "views" = prompts, "classes" = image views)
+            ALLOC(c->plpd_tf, nv * c->E, false); ALLOC(c->plpd_tfT, nv * c->E, false);
+            ALLOC(c->plpd_lkn, np * nv, false); ALLOC(c->plpd_lnk, np * nv, false);
+        }
+    }
     LoraImages im;
     const bool fresh = lora_images(c, &im);
     HIP_TRY(launch_episode_reset(c->lora_p, a->snapshot, a->exp_avg, a->exp_avg_sq, c->lora_n, c->sc, s, fresh ? &im : nullptr));
@@ -1319,11 +1424,28 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     for (int u = 0; u < a->n_updates; ++u) {
         if ((rc = forward_impl(c, nullptr, K, 1, (u == 0) ? 0 : c->c.layer_lo, (u == 0) ? a->logits0_out : nullptr, nullptr, stream, fresh)))
             return rc;
+        const unsigned char* keep = nullptr;
+        if (pl) {
+            // the destroyed views are scored against the text features of the PENDING forward (c->feat: the adapters have not moved
+            // since): image features of x' on the image context, normalised, times the normalised text features
+            const int nc = pl->n_candidates;
+            HIP_TRY(launch_entropy_loss(c->logits_nk, N, K, 0, a->mode, a->rho, a->thresh, a->margin, a->reweight, 0, c->H_buf, c->idx_buf,
+                                        c->n_buf, c->loss_buf, c->dlogits_nk, c->loss_scratch, s));
+            HIP_TRY(launch_plpd_views(a->x, c->idx_buf, c->n_buf, nc, v->S, plpd_launch_args(pl, u, v->S), v->plpd_x, v->plpd_ws, s));
+            if ((rc = forward_impl(v, v->plpd_x, nc, 0, 0, nullptr, feats, stream))) return rc;
+            HIP_TRY(launch_unit_rows(feats, nc, c->E, 1, c->plpd_tf, c->plpd_tfT, s));
+            HeadArgs h = head_args(c, nullptr, nullptr, c->plpd_lkn);
+            h.tfeat = c->plpd_tf; h.tfeatT = c->plpd_tfT; h.K = nc;
+            HIP_TRY(launch_head_logits(h, K, s));                                      // [prompts, candidates]
+            HIP_TRY(launch_transpose_f32(c->plpd_lkn, K, nc, c->plpd_lnk, s));         // -> [candidates, prompts]
+            HIP_TRY(launch_plpd_keep(c->logits_nk, c->plpd_lnk, c->idx_buf, c->n_buf, nc, N, K, pl->threshold, c->keep_buf, c->plpd_val, s));
+            keep = c->keep_buf;
+        }
         {
             Prof p(c, 5, s);
             HIP_TRY(launch_entropy_loss(c->logits_nk, N, K, a->objective, a->mode, a->rho, a->thresh, a->margin, a->reweight,
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf,
-                                        c->dlogits_nk, c->loss_scratch, s, nullptr, c->sc.i + SC_FOUND_INF));
+                                        c->dlogits_nk, c->loss_scratch, s, keep, c->sc.i + SC_FOUND_INF));
             HIP_TRY(launch_transpose_f32(c->dlogits_nk, N, K, c->dlogits_kn, s));
         }
         if ((rc = backward_impl(c, c->dlogits_kn, K, stream, true))) return rc;
@@ -1420,6 +1542,8 @@ int ttl_debug_copy(ttl_ctx* c, const char* name, int layer, void* dst, size_t by
     else if (nm == "idx") { src = c->idx_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 8; }
     else if (nm == "n_selected") { src = c->n_buf; have = 4; }
     else if (nm == "entropy") { src = c->H_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 4; }
+    else if (nm == "plpd") { src = c->plpd_val; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes) * 4; }
+    else if (nm == "keep") { src = c->keep_buf; have = (size_t)(c->c.max_views > c->c.max_classes ? c->c.max_views : c->c.max_classes); }
     else if (nm == "dh") { src = c->dh; have = M * D * 4; }
     else if (nm == "dqkv") { src = c->dqkv; have = M * c->ldwt * sizeof(op_t); }
     else if (!tr) return fail(TTL_EINVAL, "%s: layer %d is not a trained (saved) layer", name, layer);

@@ -164,6 +164,53 @@ static void image_tower(const Geo& g) {
         EXPECT(ttl_episode(sh, &b, nullptr) == 0);
         ttl_ctx_destroy(sh);
     }
+    // ---- --filter_plpd 1 inside the fused episode: auxiliary context on the shared weights, bound to the SAME adapter buffer
+    {
+        ttl_ctx* aux = nullptr;
+        EXPECT(ttl_ctx_create_shared(&cfg, c, &aux) == 0 && aux);
+        std::vector<float> grads_aux(nl);
+        std::vector<int> perm((size_t)3 * g.N * 16 > (size_t)3 * g.S * g.S ? (size_t)3 * g.N * 16 : (size_t)3 * g.S * g.S, 0);
+        ttl_plpd_args pp;
+        memset(&pp, 0, sizeof pp);
+        pp.aug_type = TTL_PLPD_PATCH; pp.threshold = 0.2f; pp.patch_len = 4; pp.perm = perm.data(); pp.n_candidates = g.N; pp.aux = aux;
+        ttl_episode_args e = a;
+        e.objective = 0; e.mode = TTL_SEL_LE_THRESH; e.n_updates = 3; e.plpd = &pp;
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);                                                  // aux not bound / no class embeddings yet
+        EXPECT(ttl_set_text_features(aux, tf.data(), g.K, 100.f, nullptr) == 0);
+        EXPECT(ttl_bind_lora(aux, lora.data(), grads_aux.data(), nl) == 0);
+        EXPECT(ttl_episode(c, &e, nullptr) == 0);
+        pp.patch_len = 3;                                                                           // S % 3 != 0: the two resize stages + scratch
+        EXPECT(ttl_episode(c, &e, nullptr) == 0);
+        pp.aug_type = TTL_PLPD_PIXEL;
+        EXPECT(ttl_episode(c, &e, nullptr) == 0);
+        pp.aug_type = TTL_PLPD_OCC; pp.perm = nullptr; pp.occlusion_size = g.S / 2; pp.row_start = 1; pp.column_start = 2;
+        EXPECT(ttl_episode(c, &e, nullptr) == 0);
+        pp.row_start = g.S;                                                                         // window outside the view
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);
+        pp.row_start = 1; pp.n_candidates = g.N + 1;
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);
+        pp.n_candidates = g.N; pp.aux = c;                                                          // the saving context cannot serve itself
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);
+        pp.aux = aux; e.objective = 1;                                                              // TPT has no PLPD stage
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);
+        e.objective = 0; pp.aug_type = TTL_PLPD_PATCH; pp.patch_len = 4;                            // 'patch' without permutations
+        EXPECT(ttl_episode(c, &e, nullptr) != 0);
+        // the pieces on their own
+        std::vector<long long> idx(g.N);
+        for (int i = 0; i < g.N; ++i) idx[i] = g.N - 1 - i;
+        int nsel = g.N;
+        std::vector<float> xp((size_t)g.N * 3 * g.S * g.S);
+        pp.aug_type = TTL_PLPD_OCC;
+        const size_t wsb = ttl_plpd_views_workspace_bytes(g.N, g.S, &pp);
+        std::vector<char> ws(wsb ? wsb : 1);
+        EXPECT(ttl_plpd_views(x.data(), g.S, (const int64_t*)idx.data(), &nsel, g.N, &pp, xp.data(), ws.data(), wsb, nullptr) == 0);
+        EXPECT(ttl_plpd_views(x.data(), g.S, (const int64_t*)idx.data(), &nsel, g.N, &pp, xp.data(), ws.data(), wsb ? wsb - 1 : 0, nullptr) != 0 || wsb == 0);
+        std::vector<unsigned char> keep(g.N);
+        std::vector<float> pv(g.N);
+        EXPECT(ttl_plpd_keep(l0.data(), l0.data(), (const int64_t*)idx.data(), &nsel, g.N, g.N, g.K, 0.2f, keep.data(), pv.data(), nullptr) == 0);
+        EXPECT(ttl_plpd_keep(l0.data(), l0.data(), (const int64_t*)idx.data(), &nsel, g.N + 1, g.N, g.K, 0.2f, keep.data(), pv.data(), nullptr) != 0);
+        ttl_ctx_destroy(aux);
+    }
     ttl_config bad = cfg; bad.rank = 8;
     EXPECT(ttl_ctx_create_shared(&bad, c, &sh) != 0);                     // invalid config
     bad = cfg; bad.layer_lo = cfg.layer_lo > 0 ? cfg.layer_lo - 1 : cfg.layer_lo + 1; bad.layer_hi = cfg.layer_hi;

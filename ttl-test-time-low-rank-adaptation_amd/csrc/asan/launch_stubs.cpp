@@ -364,3 +364,28 @@ hipError_t launch_make_views(const unsigned char* img, int H, int W, const int* 
     span_w(out, (size_t)n * 3 * S * S * 4); span_w(table, (size_t)n * 2 * S * kstride * 4);
     return hipSuccess;
 }
+
+// ---------------------------------------------------------------- PLPD filter (plpd.hip)
+size_t plpd_views_workspace_floats(int n_max, int S, int aug, int patch_len) {
+    if (aug == PLPD_OCC) return (size_t)n_max * 3;
+    if (aug == PLPD_PATCH && patch_len > 0 && S % patch_len) return 2 * (size_t)n_max * 3 * S * S;
+    return 0;
+}
+hipError_t launch_plpd_views(const float* x, const long long* idx, const int* n_sel, int n_max, int S, const PlpdArgs& p, float* out, float* ws,
+                             hipStream_t) {
+    if (n_max < 1 || S < 1) return hipErrorInvalidValue;
+    span_r(idx, (size_t)n_max * 8); span_r(n_sel, 4);
+    span_r(x, (size_t)3 * S * S * 4);                     // (which views are read depends on idx: the first one stands in)
+    span_w(out, (size_t)n_max * 3 * S * S * 4);
+    const size_t wsf = plpd_views_workspace_floats(n_max, S, p.aug, p.patch_len);
+    if (wsf) span_w(ws, wsf * 4);
+    if (p.aug == PLPD_PATCH) span_r(p.perm, (size_t)n_max * p.patch_len * p.patch_len * 4);
+    if (p.aug == PLPD_PIXEL) span_r(p.perm, (size_t)S * S * 4);
+    return hipSuccess;
+}
+hipError_t launch_plpd_keep(const float* logits, const float* logits_prime, const long long* idx, const int* n_sel, int n_max, int N, int K,
+                            float, unsigned char* keep, float* plpd_out, hipStream_t) {
+    span_r(logits, (size_t)N * K * 4); span_r(logits_prime, (size_t)n_max * K * 4); span_r(idx, (size_t)n_max * 8); span_r(n_sel, 4);
+    span_w(keep, (size_t)N); span_w(plpd_out, (size_t)n_max * 4);
+    return hipSuccess;
+}

@@ -252,6 +252,18 @@ hipError_t launch_lora_wgrad(const WgradList& L, int M, int D, int r, float* par
                              const float* scaler_f = nullptr, int* scaler_i = nullptr);
 int lora_wgrad_chunks(int M);
 
+// ---------------------------------------------------------------- PLPD filter (plpd.hip; deyo.py:115-151)
+enum { PLPD_OCC = 0, PLPD_PATCH = 1, PLPD_PIXEL = 2 };
+struct PlpdArgs { int aug; int patch_len, occ_size, row_start, col_start; const int* perm; };
+// floats of scratch launch_plpd_views needs (occ: the per-(view, channel) means; patch with S % patch_len != 0: two resize stages)
+size_t plpd_views_workspace_floats(int n_max, int S, int aug, int patch_len);
+// out[b] = destroy(x[idx[b]]) for b < *n_sel (device count; the launch is sized for n_max rows)
+hipError_t launch_plpd_views(const float* x, const long long* idx, const int* n_sel, int n_max, int S, const PlpdArgs& p, float* out,
+                             float* ws, hipStream_t s);
+// keep [N] = 0, then keep[idx[b]] = softmax(z[idx[b]])[argmax] - softmax(z'[b])[same class] > threshold for b < *n_sel
+hipError_t launch_plpd_keep(const float* logits, const float* logits_prime, const long long* idx, const int* n_sel, int n_max, int N, int K,
+                            float threshold, unsigned char* keep, float* plpd_out, hipStream_t s);
+
 // ---------------------------------------------------------------- view generator (views.hip)
 // img uint8 HWC [H][W][3]; boxes int32 [n][5] = top,left,height,width,flags (bit0 flip, bit1 base view);
 // out fp32 [n,3,S,S] normalised; table = n*2*S*kstride ints of scratch, kstride = views_kstride(H,W,S).

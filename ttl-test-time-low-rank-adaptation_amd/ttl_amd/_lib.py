@@ -43,13 +43,23 @@ class ttl_config(C.Structure):
                 ("vocab_size", C.c_int), ("lora_targets", C.c_int)]
 
 
+TTL_PLPD_OCC, TTL_PLPD_PATCH, TTL_PLPD_PIXEL = 0, 1, 2
+PLPD_AUG = {"occ": TTL_PLPD_OCC, "patch": TTL_PLPD_PATCH, "pixel": TTL_PLPD_PIXEL}
+
+
+class ttl_plpd_args(C.Structure):
+    _fields_ = [("aug_type", C.c_int), ("threshold", C.c_float), ("patch_len", C.c_int), ("occlusion_size", C.c_int),
+                ("row_start", C.c_int), ("column_start", C.c_int), ("perm", C.c_void_p), ("n_candidates", C.c_int),
+                ("aux", C.c_void_p)]
+
+
 class ttl_episode_args(C.Structure):
     _fields_ = [("x", C.c_void_p), ("n_views", C.c_int), ("n_updates", C.c_int), ("objective", C.c_int),
                 ("mode", C.c_int), ("rho", C.c_double), ("thresh", C.c_float), ("margin", C.c_float),
                 ("reweight", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("snapshot", C.c_void_p),
                 ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("logits0_out", C.c_void_p),
-                ("logits1_out", C.c_void_p), ("target", C.c_void_p), ("hits_out", C.c_void_p)]
+                ("logits1_out", C.c_void_p), ("target", C.c_void_p), ("hits_out", C.c_void_p), ("plpd", C.POINTER(ttl_plpd_args))]
 
 
 _P, _I, _F, _D, _Z = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -98,6 +108,9 @@ SIGNATURES = {
     "ttl_graph_destroy": (None, [_P]),
     "ttl_make_views_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "ttl_make_views": (_I, [_P, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _Z, _P]),
+    "ttl_plpd_views_workspace_bytes": (_Z, [_I, _I, C.POINTER(ttl_plpd_args)]),
+    "ttl_plpd_views": (_I, [_P, _I, _P, _P, _I, C.POINTER(ttl_plpd_args), _P, _P, _Z, _P]),
+    "ttl_plpd_keep": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "ttl_debug_copy": (_I, [_P, C.c_char_p, _I, _P, _Z]),
     "ttl_profile_enable": (_I, [_P, _I]),
     "ttl_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

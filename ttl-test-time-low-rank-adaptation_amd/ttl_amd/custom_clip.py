@@ -149,6 +149,12 @@ class _TextModeEngine:
     def entropy_select_loss(self, *a, **k):
         return self.txt.entropy_select_loss(*a, **k)
 
+    def plpd_views(self, *a, **k):
+        return self.img.plpd_views(*a, **k)
+
+    def plpd_keep(self, *a, **k):
+        return self.txt.plpd_keep(*a, **k)
+
     def tpt_select_loss(self, *a, **k):
         return self.txt.tpt_select_loss(*a, **k)
 

@@ -85,22 +85,19 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     reweight = float(getattr(args, "reweight_ent", 1))
     backward = None
     if getattr(args, "filter_plpd", 0):
-        # PLPD filter (deyo.py:115-151): second forward on destroyed views, keep the views whose
-        # confidence in the predicted class drops by more than plpd_threshold
+        # PLPD filter (deyo.py:115-151): second forward on destroyed views, keep the views whose confidence in the predicted class
+        # drops by more than plpd_threshold.  Views, keep mask and the loss over the survivors are HIP launches (csrc/plpd.hip);
+        # the host only draws the permutations, from torch's CPU generator exactly as the reference does
         L1 = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
                                      reweight=reweight)
-        backward = int(L1["n"].item())
+        backward = int(L1["n"].item())                                           # (the reference's own host sync: len(entropys))
         if backward == 0:
             return outputs, 0, 0                                                 # deyo.py:110-113
-        ids1 = L1["idx"][:backward]
-        x_prime = plpd_views(x[ids1].detach(), args)
+        spec = plpd_spec(args)
+        perm = draw_plpd_perms(spec, 1, backward, x.shape[-1], outputs.device)
+        x_prime = eng.plpd_views(x, L1["idx"], L1["n"], backward, spec, perm)    # deyo.py:116-134
         outputs_prime = model._aux_engine().forward(x_prime, save=False)         # deyo.py:135
-        prob = outputs[ids1].softmax(1)
-        prob_prime = outputs_prime.softmax(1)
-        cls1 = prob.argmax(dim=1)
-        plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_prime, 1, cls1.reshape(-1, 1))).reshape(-1)
-        keep = torch.zeros(outputs.shape[0], dtype=torch.uint8, device=outputs.device)
-        keep[ids1] = (plpd > args.plpd_threshold).to(torch.uint8)                # deyo.py:146
+        keep, _ = eng.plpd_keep(outputs, outputs_prime, L1["idx"], L1["n"], backward, spec["threshold"])     # deyo.py:137-146
         L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
                                     reweight=reweight, keep=keep)
     else:
@@ -120,8 +117,40 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     return outputs, (n if backward is None else backward), n
 
 
+def plpd_spec(args):
+    """The PLPD arguments of the reference's CLI (ttl.py argparse: --aug_type, --plpd_threshold, --patch_len, --occlusion_size,
+    --row_start, --column_start) as the dict TTLEngine.plpd_struct takes."""
+    return dict(aug_type=getattr(args, "aug_type", "patch"), threshold=float(getattr(args, "plpd_threshold", 0.2)),
+                patch_len=int(getattr(args, "patch_len", 4)), occlusion_size=int(getattr(args, "occlusion_size", 0) or 0),
+                row_start=int(getattr(args, "row_start", 0) or 0), column_start=int(getattr(args, "column_start", 0) or 0))
+
+
+def draw_plpd_perms(spec, n_updates, n_candidates, size, device):
+    """The random permutations of ``n_updates`` PLPD steps, drawn from torch's CPU generator in the reference's call order —
+    'patch': torch.argsort(torch.rand(B, patch_len**2), dim=-1) per step (deyo.py:127), 'pixel': torch.randperm(S*S) per step
+    (deyo.py:133) — as ONE device int32 tensor [n_updates, ...]; 'occ' draws nothing (None)."""
+    if spec["aug_type"] == "patch":
+        P = spec["patch_len"] ** 2
+        perms = [torch.argsort(torch.rand(n_candidates, P), dim=-1) for _ in range(n_updates)]
+    elif spec["aug_type"] == "pixel":
+        perms = [torch.randperm(size * size) for _ in range(n_updates)]
+    else:
+        return None
+    return torch.stack(perms).to(dtype=torch.int32).contiguous().to(device, non_blocking=True)
+
+
+def plpd_candidates(args, n_views, n_classes):
+    """How many views the FIRST selection stage yields, when the host can know it without looking at the logits (the row count of
+    the reference's torch.rand(B, P)): int(N * selection_p) in top-rho mode (deyo.py:105); N in threshold mode, where
+    H <= ln K <= ln 1000 holds for every view as long as K <= 1000 (deyo.py:107).  None: data-dependent -> step-wise path."""
+    if getattr(args, "filter_ent", 0):
+        return int(n_views * args.selection_p)
+    return n_views if n_classes <= 1000 else None
+
+
 def plpd_views(x_prime, args):
-    """The view-destroying transform of deyo.py:118-134 (host-side torch ops, like the reference).
+    """The view-destroying transform of deyo.py:118-134 as host-side torch ops — the restatement the tests hold the HIP kernels
+    (csrc/plpd.hip, TTLEngine.plpd_views) against, and what autograd-formulation callers may use; NOT on the product path.
     'patch': resize to a multiple of patch_len, permute the patch_len^2 patches of every view with
     torch.argsort(torch.rand(B, P)) on the CPU generator (the reference's RNG call), resize back;
     'pixel': one random pixel permutation shared by the batch; 'occ': fill a window with the view mean.

@@ -344,9 +344,14 @@ class EpisodeRunner:
     loss, LoRA backward, AdamW) -> adapted 1-view inference, as one enqueue (ttl_episode)."""
 
     def __init__(self, model, args):
-        if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
-            raise NotImplementedError("the fused episode has no PLPD stage: use ttl.test_time_tuning (step-wise path) for "
-                                      "--filter_plpd 1; reweight_plpd is commented out in the reference (deyo.py:176)")
+        if getattr(args, "reweight_plpd", 0):
+            raise NotImplementedError("reweight_plpd is commented out in the reference (deyo.py:176)")
+        self.plpd = None
+        if getattr(args, "filter_plpd", 0):      # deyo.py:115-151 inside the fused episode (round 5): ttl_episode_args.plpd
+            from .deyo import plpd_spec
+            if not (bool(args.deyo_selection) and args.lora_encoder != 'prompt'):
+                raise NotImplementedError("the PLPD filter belongs to the DeYO objective (deyo.py:115)")
+            self.plpd = plpd_spec(args)
         self.model = model
         self.args = args
         self.eng = model._ensure_engine()
@@ -361,7 +366,18 @@ class EpisodeRunner:
     def __call__(self, views):
         """views [N,3,S,S] (view 0 = the un-augmented image) -> logits [1,K] with adapted weights."""
         m = self.model
-        return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
+        if self.plpd is None:
+            return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
+        from .deyo import draw_plpd_perms, plpd_candidates
+        nc = plpd_candidates(self.args, views.shape[0], self.eng.n_classes)
+        if not nc:
+            raise NotImplementedError("the first-stage selection count is data-dependent here (threshold mode with more than 1000 "
+                                      "classes) or zero: use ttl.test_time_tuning (step-wise path)")
+        text = m.lora_encoder == 'text'
+        perm = draw_plpd_perms(self.plpd, self.kw["n_updates"], nc, views.shape[-1], self.eng.device)
+        st = self.eng.plpd_struct(self.plpd, perm, nc, None if text else m._aux_engine()) if not text else \
+            self.eng.txt.plpd_struct(self.plpd, perm, nc, None)
+        return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, plpd=st, **self.kw)
 
 
 class EpisodePipeline:
@@ -403,6 +419,7 @@ class EpisodePipeline:
                                    else torch.cuda.Stream(device=dev),
                                    acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
         self._next = 0
+        self._text_features, self._logit_scale, self._text_version = text_features, logit_scale_exp, 0     # (for the PLPD auxiliary contexts)
         # use_graph: every slot replays its episode as ONE hipGraphLaunch (captured on first use per argument set)
         # over a slot-owned copy of the views: the host then spends ~0.1 ms per image instead of ~2.7 ms of kernel
         # enqueues, which is what bounds runs with few views (8 views = < 1 ms of GPU time).  Image-tower slots only.
@@ -419,6 +436,8 @@ class EpisodePipeline:
         if n_new > self.max_classes:
             raise ValueError("more classes than the pipeline was built for")
         self.synchronize()
+        if text_features is not None:
+            self._text_features, self._logit_scale, self._text_version = text_features, logit_scale_exp, self._text_version + 1
         for sl in self.slots:
             if prompts is not None:
                 sl["eng"].txt.set_prompts(prompts)
@@ -434,7 +453,38 @@ class EpisodePipeline:
         self._next = 0
         torch.cuda.synchronize(self.slots[0]["flat"].device)
 
-    def submit(self, views, target=None, persistent_input=False, want_output=True, **episode_kw):
+    def _plpd_struct(self, sl, plpd, n_updates, views):
+        """ttl_plpd_args of one image on slot ``sl``: the slot's auxiliary context (image mode; created on first use on the
+        owner's weight images, bound to the slot's adapter buffer) and this image's permutations, drawn on the host like the
+        reference draws them and copied into a slot-owned device buffer (whose address a captured graph keeps)."""
+        from .deyo import draw_plpd_perms
+        from .engine import TTLEngine
+        spec, nc = plpd["spec"], int(plpd["n_candidates"])
+        eng = sl["eng"]
+        text = hasattr(eng, "txt")
+        aux = None
+        if not text:
+            aux = sl.get("aux")
+            if aux is None:
+                aux = sl["aux"] = TTLEngine(eng.cfg, eng.max_views, eng.max_classes, eng.device, eng.precision,
+                                            share_from=self.slots[0]["eng"])          # (slot 0 owns its weight images)
+                aux.bind_lora(sl["flat"])
+                sl["aux_classes"] = None
+            if sl.get("aux_classes") != self._text_version:
+                aux.set_text_features(self._text_features, self._logit_scale)
+                sl["aux_classes"] = self._text_version
+        perm = draw_plpd_perms(spec, n_updates, nc, views.shape[-1], "cpu")
+        buf = None
+        if perm is not None:
+            buf = sl.get("permbuf")
+            if buf is None or buf.shape != perm.shape:
+                buf = sl["permbuf"] = torch.empty(perm.shape, dtype=torch.int32, device=views.device)
+                sl["gkey"] = None                       # a captured graph holds the old buffer's address
+            buf.copy_(perm.pin_memory(), non_blocking=True)      # on the slot's stream, ahead of the episode
+        owner = eng.txt if text else eng
+        return owner.plpd_struct(spec, buf, nc, aux)
+
+    def submit(self, views, target=None, persistent_input=False, want_output=True, plpd=None, **episode_kw):
         """Enqueue one episode on the next slot's stream; returns the (future) logits1 tensor [1,K] (None with
         ``want_output=False``: the caller only wants the accuracy accumulator — bench.py — and no copy is made).
         With ``target`` (device int64 [1]) the slot's [hits1, hits5, count] accumulator is updated INSIDE the episode's enqueue
@@ -454,8 +504,11 @@ class EpisodePipeline:
                                     "coerce with .to(device, dtype=torch.int64)")
             target.record_stream(sl["stream"])
         with torch.cuda.stream(sl["stream"]):
+            if plpd is not None:       # --filter_plpd 1 (deyo.py:115-151) inside the fused episode
+                episode_kw = dict(episode_kw, plpd=self._plpd_struct(sl, plpd, int(episode_kw.get("n_updates", 1)), views))
             if self.use_graph:
-                key = (tuple(views.shape), target is not None, tuple(sorted(episode_kw.items())))
+                key = (tuple(views.shape), target is not None, tuple(sorted((k, v) for k, v in episode_kw.items() if k != "plpd")),
+                       None if plpd is None else (tuple(sorted(plpd["spec"].items())), plpd["n_candidates"]))
                 if sl.get("gkey") != key:          # another shape / argument set: every captured graph of the slot is stale
                     sl["gkey"], sl["graph"], sl["xbuf"], sl["graphs_in_place"] = key, None, None, {}
                     sl["obuf"] = torch.empty((1, sl["eng"].n_classes), dtype=torch.float32, device=views.device)
@@ -504,4 +557,6 @@ class EpisodePipeline:
 
     def close(self):
         for sl in reversed(self.slots):          # the owner of the shared weight images (slot 0) goes last
+            if sl.get("aux") is not None:
+                sl["aux"].close()
             sl["eng"].close()

@@ -193,6 +193,46 @@ class TTLEngine:
                                                     _ptr(out["dlogits"]), _stream()))
         return out
 
+    # ---- PLPD filter of DeYO (deyo.py:115-151) on the device: destroyed views, keep mask; include/ttl_hip.h ttl_plpd_*
+    @staticmethod
+    def plpd_struct(spec, perm=None, n_candidates=0, aux=None):
+        """spec: dict(aug_type 'occ' | 'patch' | 'pixel', threshold, patch_len, occlusion_size, row_start, column_start)."""
+        a = _lib.ttl_plpd_args()
+        a.aug_type = _lib.PLPD_AUG[spec["aug_type"]]
+        a.threshold = float(spec.get("threshold", 0.0))
+        a.patch_len = int(spec.get("patch_len", 0) or 0)
+        a.occlusion_size, a.row_start, a.column_start = (int(spec.get(k, 0) or 0) for k in ("occlusion_size", "row_start", "column_start"))
+        if perm is not None:
+            assert perm.is_cuda and perm.dtype == torch.int32 and perm.is_contiguous()
+            a.perm = perm.data_ptr()
+        a.n_candidates = int(n_candidates)
+        a.aux = aux._h if aux is not None else None
+        return a
+
+    def plpd_views(self, x, idx, n_sel, n_max, spec, perm=None):
+        """x' = destroy(x[idx[:n]]) (deyo.py:116-134) -> [n_max,3,S,S]; idx int64 / n_sel int32 are the DEVICE outputs of the first
+        selection stage, perm the host-drawn permutations of this update (device int32; draw_plpd_perms)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        S = x.shape[-1]
+        a = self.plpd_struct(spec, perm, n_max)
+        out = torch.empty((n_max, 3, S, S), dtype=torch.float32, device=self.device)
+        wsb = int(self.lib.ttl_plpd_views_workspace_bytes(n_max, S, C.byref(a)))
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_plpd_views(_ptr(x), S, _ptr(idx), _ptr(n_sel), n_max, C.byref(a), _ptr(out), _ptr(ws), wsb, _stream()))
+        return out
+
+    def plpd_keep(self, logits, logits_prime, idx, n_sel, n_max, threshold):
+        """-> (keep uint8 [N], plpd fp32 [n_max]): keep[idx[b]] = softmax(z[idx[b]])[argmax] - softmax(z'[b])[same class] > threshold."""
+        z = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        zp = logits_prime.to(device=self.device, dtype=torch.float32).contiguous()
+        keep = torch.empty(z.shape[0], dtype=torch.uint8, device=self.device)
+        val = torch.empty(n_max, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_plpd_keep(_ptr(z), _ptr(zp), _ptr(idx), _ptr(n_sel), n_max, z.shape[0], z.shape[1], float(threshold),
+                                               _ptr(keep), _ptr(val), _stream()))
+        return keep, val
+
     def adamw_step(self, params, grads, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                    n_selected=None):
         with torch.cuda.device(self.device):
@@ -249,8 +289,9 @@ class TTLEngine:
 
     def episode(self, x, snapshot, m, v, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH, rho=0.1,
                 thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                want_logits0=False, target=None, hits=None, out=None):
+                want_logits0=False, target=None, hits=None, out=None, plpd=None):
         """One whole test image (ttl.py:338-352) as a single enqueue; returns logits1 [1,K] (and logits0).
+        plpd: a ttl_plpd_args (``plpd_struct``) — --filter_plpd 1 inside the episode (aux engine, host-drawn permutations).
         target (device int64 [1]) + hits (device int64 [3]): top-1 / top-5 hit of the adapted prediction and the image count are
         added to ``hits`` on the device (utils/tools.py:88-102), inside the same enqueue.  out: write logits1 there ([1,K])."""
         import math
@@ -270,6 +311,8 @@ class TTLEngine:
         a.logits0_out = l0.data_ptr() if want_logits0 else None
         a.logits1_out = l1.data_ptr()
         self._set_target(a, target, hits)
+        if plpd is not None:
+            a.plpd = C.pointer(plpd)
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode(self._h, C.byref(a), _stream()))
         return (l1, l0) if want_logits0 else l1
@@ -285,7 +328,7 @@ class TTLEngine:
 
     def episode_graph(self, x_buf, snapshot, m, v, logits1_buf, *, n_updates=1, objective="deyo", mode=_lib.TTL_SEL_LE_THRESH,
                       rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                      target=None, hits=None):
+                      target=None, hits=None, plpd=None):
         """Capture the episode over FIXED buffers (x_buf [N,3,S,S], logits1_buf [1,K], snapshot / m / v, and — for the on-device
         hit count — target int64 [1] / hits int64 [3]) into a HIP graph on the current (non-default) stream; returns a callable
         that replays it on the current stream.  The capture itself runs the episode once on whatever the buffers hold (that run
@@ -302,6 +345,8 @@ class TTLEngine:
         a.snapshot, a.exp_avg, a.exp_avg_sq = snapshot.data_ptr(), m.data_ptr(), v.data_ptr()
         a.logits0_out, a.logits1_out = None, logits1_buf.data_ptr()
         self._set_target(a, target, hits)
+        if plpd is not None:          # (the permutation buffer it points to is baked into the graph: refill it in place)
+            a.plpd = C.pointer(plpd)
         g = C.c_void_p()
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode_capture(self._h, C.byref(a), _stream(), C.byref(g)))
@@ -398,7 +443,7 @@ class TextTowerEngine(TTLEngine):
 
     def episode(self, image_engine: TTLEngine, x, snapshot, m, v, *, n_updates=1, objective="deyo",
                 mode=_lib.TTL_SEL_LE_THRESH, rho=0.1, thresh=None, margin=0.4, reweight=1.0, lr=5e-3, betas=(0.9, 0.999),
-                eps=1e-8, weight_decay=1e-2, want_logits0=False, target=None, hits=None):
+                eps=1e-8, weight_decay=1e-2, want_logits0=False, target=None, hits=None, plpd=None):
         """Whole text-mode episode as one enqueue; ``image_engine`` is an adapter-less image-tower engine."""
         import math
         self._skipped_seen = None
@@ -417,6 +462,8 @@ class TextTowerEngine(TTLEngine):
         a.logits0_out = l0.data_ptr() if want_logits0 else None
         a.logits1_out = l1.data_ptr()
         self._set_target(a, target, hits)
+        if plpd is not None:
+            a.plpd = C.pointer(plpd)
         with torch.cuda.device(self.device):
             self._check(self.lib.ttl_episode_text(self._h, image_engine._h, C.byref(a), _stream()))
         self.n_views = n

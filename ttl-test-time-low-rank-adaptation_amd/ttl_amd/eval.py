@@ -25,12 +25,10 @@ from .driver import EpisodePipeline, ImageShard, dist_env
 
 
 def episode_kwargs_from_args(args):
-    """Reference CLI semantics -> fused-episode arguments (incl. tta_steps**2 on the DeYO branch, Q6).  The fused
-    ttl_episode has no PLPD stage: callers route ``--filter_plpd 1`` to the step-wise host loop instead."""
+    """Reference CLI semantics -> fused-episode arguments (incl. tta_steps**2 on the DeYO branch, Q6).  ``--filter_plpd 1``
+    travels separately (EpisodePipeline.submit(plpd=...): per-image permutations)."""
     if getattr(args, "reweight_plpd", 0):
         raise NotImplementedError("reweight_plpd: the term is commented out in the reference (deyo.py:176)")
-    if getattr(args, "filter_plpd", 0):
-        raise NotImplementedError("filter_plpd needs the step-wise path (ttl.test_time_tuning): the fused episode has no PLPD stage")
     deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
     return dict(n_updates=(args.tta_steps ** 2 if deyo else args.tta_steps), objective="deyo" if deyo else "tpt",
                 mode=1 if getattr(args, "filter_ent", 0) else 0, rho=args.selection_p, margin=args.deyo_margin_e0,
@@ -51,11 +49,20 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
     from .deyo import _adam_hparams
     model.eval()
     eng = model._ensure_engine()
+    plpd = None
     if getattr(args, "filter_plpd", 0) or getattr(args, "reweight_plpd", 0):
-        # --filter_plpd 1 (deyo.py:115-151): the second forward on destroyed views and the host-side keep mask sit between
-        # forward and backward, so these runs take the reference-shaped per-image loop (ttl.py:338-352) on the step-wise
-        # entry points instead of being silently evaluated as plain DeYO
-        return _host_loop_eval(val_loader, model, optimizer, optim_state, scaler, args, rank, world, gpu_augmenter)
+        # --filter_plpd 1 (deyo.py:115-151).  Round 5: the destroyed views, the second forward and the keep mask are a stage of the
+        # fused episode (ttl_episode_args.plpd) whenever the host knows how many views the first selection stage yields (always in
+        # top-rho mode; in threshold mode for K <= 1000 classes) and the objective is DeYO; otherwise — and with
+        # TTL_PLPD_STEPWISE=1 — the reference-shaped per-image loop (ttl.py:338-352) on the step-wise entry points
+        import os
+        from .deyo import plpd_candidates, plpd_spec
+        deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
+        n_cls0 = int(model.prompt_learner.tokenized_prompts.shape[0]) if model.lora_encoder == 'text' else int(model.text_features.shape[0])
+        ok = deyo and not getattr(args, "reweight_plpd", 0) and plpd_candidates(args, 64, n_cls0) and os.environ.get("TTL_PLPD_STEPWISE", "0") != "1"
+        if not ok:
+            return _host_loop_eval(val_loader, model, optimizer, optim_state, scaler, args, rank, world, gpu_augmenter)
+        plpd = plpd_spec(args)
     _, lr, betas, eps, wd = _adam_hparams(optimizer, model)
     kw = episode_kwargs_from_args(args)
     kw.update(lr=lr, betas=betas, eps=eps, weight_decay=wd)
@@ -104,7 +111,11 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
             if images.dim() == 5:
                 images = images.squeeze(0)
         tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev, dtype=torch.int64)     # the device-side hit count reads an int64 label
-        pipe.submit(images, target=tgt, **kw)
+        if plpd is not None:
+            from .deyo import plpd_candidates
+            pipe.submit(images, target=tgt, plpd=dict(spec=plpd, n_candidates=plpd_candidates(args, images.shape[0], n_cls)), **kw)
+        else:
+            pipe.submit(images, target=tgt, **kw)
         if progress is not None:
             progress.note(i, lambda: (pipe.totals() + acc0).tolist())
     totals = pipe.totals() + acc0
