@@ -248,8 +248,9 @@ typedef struct ttl_episode_args {
     const int64_t* target;
     int64_t* hits_out;
     /* --filter_plpd 1 inside the fused episode (DeYO objective only); NULL = no PLPD stage.  Per update: first-stage selection ->
-     * destroyed views -> second forward -> keep mask -> loss over the survivors; "idx" / "n_selected" of ttl_debug_copy then hold
-     * the SECOND-stage list (filter_ids_1[filter_ids_2]). */
+     * destroyed views -> second forward -> keep mask -> loss over the survivors.  ttl_debug_copy afterwards: "idx" = the FIRST-stage
+     * list (n_candidates entries, the reference's order), "keep" = uint8 mask over the views, "plpd" = fp32 PLPD value per candidate,
+     * "n_selected" = number of survivors (len(filter_ids_2)). */
     const ttl_plpd_args* plpd;
 } ttl_episode_args;
 int ttl_episode(ttl_ctx* ctx, const ttl_episode_args* args, void* stream);

@@ -296,16 +296,19 @@ def test_aux_context_follows_a_label_set_of_the_same_size():
     assert torch.equal(model._aux_engine().forward(x[:2]), z2)
 
 
-def test_eval_routes_filter_plpd_to_the_stepwise_loop():
+def test_eval_with_filter_plpd_equals_the_reference_shaped_loop():
     """test_time_adapt_eval with --filter_plpd 1 == the reference-shaped per-image loop with the PLPD filter (not a silent
-    plain-DeYO run); the fused runner refuses the flag."""
+    plain-DeYO run).  Since round 5 the evaluation loop runs the filter as a stage of the fused episode (csrc/plpd.hip,
+    ttl_episode_args.plpd); flags the fused stage does not cover are refused, not ignored."""
     from ttl_amd.eval import test_time_adapt_eval, SyntheticViews
     from ttl_amd.ttl import test_time_tuning
     from ttl_amd.driver import topk_hits, EpisodeRunner
     g, cfg, model, opt, opt_state, x = build("tiny_deyo")
     args = ref_args(filter_plpd=1, plpd_threshold=-1.0, aug_type="occ", occlusion_size=8, row_start=4, column_start=4, patch_len=4)
     with pytest.raises(NotImplementedError):
-        EpisodeRunner(model, args)
+        EpisodeRunner(model, ref_args(filter_plpd=1, reweight_plpd=1))
+    with pytest.raises(NotImplementedError):
+        EpisodeRunner(model, ref_args(filter_plpd=1, deyo_selection=False))          # TPT has no PLPD stage (deyo.py:115)
     data = SyntheticViews(cfg, 4, 8, 10, seed=5)
     hits = torch.zeros(2, dtype=torch.int64)
     outs = []

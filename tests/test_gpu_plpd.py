@@ -87,6 +87,18 @@ def test_plpd_keep_vs_the_reference_formula():
     eng.close()
 
 
+def survivors(eng, n_views, n_candidates, n_expected, g):
+    """The second-stage list filter_ids_1[filter_ids_2] (deyo.py:146-151) as the context holds it after a PLPD update: "idx" is the
+    FIRST-stage list (the reference's order), "keep" the mask over views, "n_selected" the number of survivors."""
+    n = int(eng.debug_copy("n_selected", 0, (1,), np.int32)[0])
+    first = eng.debug_copy("idx", 0, (n_views,), np.int64)[:n_candidates]
+    assert np.array_equal(first, np.asarray(g["idx"]).reshape(-1))                 # first stage: the reference's list, order included
+    keep = eng.debug_copy("keep", 0, (n_views,), np.uint8)
+    out = first[keep[first] != 0]
+    assert len(out) == n
+    return out
+
+
 def _spec_of(g):
     aug = str(g["aug_type"]) if "aug_type" in g.files else "patch"
     return dict(aug_type=aug, threshold=float(g["plpd_threshold"]), patch_len=int(g["patch_len"]),
@@ -121,7 +133,7 @@ def test_fused_episode_with_a_plpd_stage_vs_reference(name, precision):
     tol = {"strict": 1e-5, "fp16": 1e-3, "bf16": 3e-2}[precision]
     assert max_rel(l0.cpu().numpy(), g["logits0"]) < tol
     plpd = eng.debug_copy("plpd", 0, (B,), np.float32)
-    idx2, _ = eng.last_selection(x.shape[0])
+    idx2 = survivors(eng, x.shape[0], B, len(np.asarray(g["idx2"]).reshape(-1)), g)
     ptol = {"strict": 2e-5, "fp16": 3e-3, "bf16": 5e-2}[precision]
     assert np.abs(plpd - g["plpd"]).max() < ptol, np.abs(plpd - g["plpd"]).max()
     # the surviving set: exactly the reference's unless a candidate's PLPD sits within the build's noise of the threshold
@@ -168,9 +180,9 @@ def test_fused_text_mode_episode_with_a_plpd_stage_vs_reference(precision):
     eng = model._ensure_engine()
     B = len(np.asarray(g["idx"]).reshape(-1))
     plpd = eng.txt.debug_copy("plpd", 0, (B,), np.float32)
-    ptol = 2e-5 if precision == "strict" else 3e-3
+    ptol = 2e-5 if precision == "strict" else 8e-3        # (fp16: both towers carry operand noise in this mode)
     assert np.abs(plpd - g["plpd"]).max() < ptol, np.abs(plpd - g["plpd"]).max()
-    idx2, _ = eng.txt.last_selection(x.shape[0])
+    idx2 = survivors(eng.txt, x.shape[0], B, None, g)
     if np.abs(np.asarray(g["plpd"]) - float(g["plpd_threshold"])).min() > ptol:
         assert np.array_equal(np.sort(idx2), np.sort(np.asarray(g["idx2"]).reshape(-1)))
     assert max_rel(out.cpu().numpy(), g["logits1"]) < (1e-4 if precision == "strict" else 3e-2)
