@@ -79,9 +79,15 @@ def main(src, tag, suffix=""):
     if sweep:
         other["streams_sweep_bf16"] = sweep
     json.dump(other, open_w(f"{out}/{tag}_other_configs.json"), indent=1)
-    for f in ("pmc_summary.txt", "pmc_memory_path.txt", "gemm_traffic.json", "class_cost_in_flight.txt", "parity_per_fixture.txt"):
+    for f in ("pmc_summary.txt", "pmc_memory_path.txt", "gemm_traffic.json", "class_cost_in_flight.txt"):
         if os.path.exists(f"{src}/{f}"):
             shutil.copy(f"{src}/{f}", named(f"{out}/{tag}_{f}"))
+    for f in ("parity_per_fixture.txt", "plpd_trace_summary.txt"):      # tables over ALL builds: no build suffix
+        if os.path.exists(f"{src}/{f}"):
+            with open(f"{src}/{f}") as fi, open(f"{out}/{tag}_{f}", "w") as fo:
+                fo.writelines(l for l in fi if "amdgpu.ids" not in l)
+    if os.path.exists(f"{src}/torch_stack.json"):
+        shutil.copy(f"{src}/torch_stack.json", f"{out}/{tag}_torch_stack_reference_point.json")
     # HBM-bound kernels: per-launch durations from the 1-stream kernel trace
     trace = [os.path.join(dp, f) for dp, _, fs in os.walk(f"{src}/prof1") for f in fs if f.endswith("kernel_trace.csv")]
     if trace:

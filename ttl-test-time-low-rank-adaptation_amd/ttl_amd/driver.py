@@ -479,8 +479,17 @@ class EpisodePipeline:
             buf = sl.get("permbuf")
             if buf is None or buf.shape != perm.shape:
                 buf = sl["permbuf"] = torch.empty(perm.shape, dtype=torch.int32, device=views.device)
+                sl["permpin"] = [torch.empty(perm.shape, dtype=torch.int32).pin_memory() for _ in range(2)]     # (pinning per image costs ms)
+                sl["permev"] = [None, None]
+                sl["permi"] = 0
                 sl["gkey"] = None                       # a captured graph holds the old buffer's address
-            buf.copy_(perm.pin_memory(), non_blocking=True)      # on the slot's stream, ahead of the episode
+            k = sl["permi"] = sl["permi"] ^ 1            # two staging buffers: the copy of image i-2 of this slot has long completed
+            if sl["permev"][k] is not None:
+                sl["permev"][k].synchronize()
+            sl["permpin"][k].copy_(perm)
+            buf.copy_(sl["permpin"][k], non_blocking=True)       # on the slot's stream, ahead of the episode
+            sl["permev"][k] = torch.cuda.Event()
+            sl["permev"][k].record()
         owner = eng.txt if text else eng
         return owner.plpd_struct(spec, buf, nc, aux)
 
