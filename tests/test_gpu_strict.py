@@ -212,3 +212,61 @@ def test_strict_build_residual_stream_taps(name):
             h, ref = h[:, 0], ref[:, 0]
         bound(f"strict/{name}/tap_layer{i}", max_rel(h, ref), TAP_TOL)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_text_deyo", "tiny_text_topk", "b16_text_n8_k10", "b16_text_n64_k200"])
+def test_strict_build_text_tower_mode(name):
+    """--lora_encoder text (clip/custom_clip.py:602-607, 672-678) on the strict build against the reference-written text fixtures:
+    both towers in fp32 products (causal attention, end-of-text pooling, roles swapped in the head), the fused ttl_episode_text.
+    Same tolerances as the image tower: logits 1e-5, every gradient tensor 1e-4, weights element-wise 1e-3 (eps-steep rule)."""
+    from helpers import load_text_case
+    from test_gpu_text import make, split as tsplit
+    g, vcfg, tcfg, Wv, Wt, x, ids, lora0 = load_text_case(name)
+    kw = episode_kwargs(g)
+    assert kw["n_updates"] == 1
+    N, K = x.shape[0], ids.shape[0]
+    img, txt, flat, names = make(vcfg, tcfg, Wv, Wt, lora0, N, K, precision="strict")
+    txt.set_prompts(ids)
+    snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    l1, l0 = txt.episode(img, torch.from_numpy(x).cuda(), snap, m, v, n_updates=1, objective=kw["objective"],
+                         mode=1 if kw["mode"] == "topk" else 0, rho=kw["rho"], margin=kw["margin"], lr=kw["lr"], want_logits0=True)
+    torch.cuda.synchronize()
+    z0, z1 = l0.cpu().numpy(), l1.cpu().numpy()
+    bound(f"strict/{name}/logits0", max_rel(z0, g["logits0"]), LOGIT_TOL)
+    idx, _ = txt.last_selection(N)
+    assert np.array_equal(np.sort(idx), np.sort(np.asarray(g["idx"]).reshape(-1)))
+    lora1, grads = tsplit(flat, lora0, names), tsplit(txt.grads, lora0, names)
+    worst = 0.0
+    for k in names:
+        gref = g["grad/" + k]
+        if np.abs(gref).max() == 0:
+            assert not grads[k].any(), k
+            continue
+        e = max_rel(grads[k], gref)
+        worst = max(worst, e)
+        assert e < GRAD_TOL, (name, k, e)
+        check_weights(name, k, lora1[k], g["lora1/" + k], gref, grads[k], kw["lr"])
+    bound(f"strict/{name}/grad_worst", worst, GRAD_TOL)
+    bound(f"strict/{name}/logits1", max_rel(z1, g["logits1"]), LOGIT1_TOL)
+    print(f"[strict] {name}: logits0 {max_rel(z0, g['logits0']):.2e} logits1 {max_rel(z1, g['logits1']):.2e} worst gradient {worst:.2e}")
+    img.close(); txt.close()
+
+
+@pytest.mark.parametrize("name", ["l14_n64_k200", "b16_n64_k1000_ent0", "b16_n64_k200_outliers", "b16_n64_k200_outliers_ent1"])
+def test_strict_build_remaining_full_size_fixtures(name):
+    """The other reference-written full-size fixtures (BASELINE config 4 at its 64 views: ViT-L/14, T = 257, D = 1024; K = 1000
+    with every view selected; CLIP-like outlier weights): logits and gradients at the strict tolerances."""
+    g, cfg, kw, x, lora0, eng, flat, names, z0, z1 = run_episode(name)
+    bound(f"strict/{name}/logits0", max_rel(z0, g["logits0"]), LOGIT_TOL)
+    hip_idx, _ = eng.last_selection(x.shape[0])
+    assert np.array_equal(np.sort(hip_idx), np.sort(np.asarray(g["idx"]).reshape(-1)))
+    lora1, grads = split(flat, lora0, names), split(eng.grads, lora0, names)
+    worst = 0.0
+    for k in names:
+        gref = g["grad/" + k]
+        if np.abs(gref).max() > 0:
+            worst = max(worst, max_rel(grads[k], gref))
+            check_weights(name, k, lora1[k], g["lora1/" + k], gref, grads[k], kw["lr"])
+    bound(f"strict/{name}/grad_worst", worst, GRAD_TOL)
+    bound(f"strict/{name}/logits1", max_rel(z1, g["logits1"]), LOGIT1_TOL)
+    eng.close()
