@@ -25,7 +25,9 @@ def main():
     out = {"note": "tools/derive_test_bounds.py: bound = measured-on-MI355X x %.1f (3 significant digits, floor %g); "
                    "regenerate after any kernel change that moves a summation order" % (MARGIN, FLOOR),
            "margin": MARGIN, "measured": {k: meas[k] for k in sorted(meas)},
-           "bounds": {k: max(up3(meas[k] * MARGIN), FLOOR) for k in sorted(meas)}}
+           # strict/ keys (fp32 build, tests/test_gpu_strict.py) measure fp32 summation-order noise, 1e-6 ... 1e-5 against documented
+           # ceilings of 1e-5 ... 1e-4: x 3 and a floor of 5e-6, so that a harmless re-association does not fail them
+           "bounds": {k: (max(up3(meas[k] * 3.0), 5e-6) if k.startswith("strict/") else max(up3(meas[k] * MARGIN), FLOOR)) for k in sorted(meas)}}
     dst = os.path.join(ROOT, "tests", "golden", "bounds.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
