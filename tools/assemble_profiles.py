@@ -71,13 +71,13 @@ def main(src, tag, suffix=""):
             other[key] = [l.strip() for l in open(f"{src}/{f}").read().strip().split("\n")
                           if l.strip() and "amdgpu.ids" not in l][-6:]
     sweep = {}
-    for n in (2, 3, 4):          # stream-count sweep of the bf16 build (collected after the PMC passes, same lease)
+    for n in (2, 3, 4, 6):       # stream-count sweep of the build named by the suffix (tools/r05_sweeps.sh, one lease)
         d = last_json(f"{src}/bench_streams{n}.json")
         if d:
             sweep[f"streams{n}"] = {k: d[k] for k in ("value", "value_min", "value_max", "ms_per_step", "host_enqueue_ms_per_image", "repeats", "steps")}
             sweep[f"streams{n}"]["hip_graph"] = d["protocol"]["hip_graph"]
     if sweep:
-        other["streams_sweep_bf16"] = sweep
+        other["streams_sweep" + sfx] = sweep
     json.dump(other, open_w(f"{out}/{tag}_other_configs.json"), indent=1)
     for f in ("pmc_summary.txt", "pmc_memory_path.txt", "gemm_traffic.json", "class_cost_in_flight.txt"):
         if os.path.exists(f"{src}/{f}"):
