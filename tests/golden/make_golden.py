@@ -29,6 +29,11 @@ import _ref_harness as H  # noqa: E402
 
 CIFAR10 = ["airplane", "automobile", "bird", "cat", "deer", "dog", "frog", "horse", "ship", "truck"]
 
+# chosen after a first run with the CLI default 0.2 so that the second stage keeps about half of the 64 candidates of this synthetic
+# model (its 64 PLPD values run from -0.26 to +0.04; -0.056 sits in the widest gap near the median, 0.0043 from either neighbour: 25 views
+# survive); TTL_PLPD_B16_THRESHOLD overrides it for that first look
+PLPD_B16_THRESHOLD = float(os.environ.get("TTL_PLPD_B16_THRESHOLD", "-0.056"))
+
 CASES = {
     # name: (arch, n_views, n_classes, overrides)
     "tiny_deyo": ("tiny", 8, 10, {}),
@@ -85,6 +90,10 @@ CASES = {
     "b16_n64_k200_outliers": ("ViT-B/16", 64, 200, {"weights_variant": "outliers"}),
     "b16_n64_k200_outliers_ent1": ("ViT-B/16", 64, 200, {"weights_variant": "outliers", "filter_ent": 1}),
     "tiny_outliers": ("tiny", 8, 10, {"weights_variant": "outliers"}),
+    # round 5: the TPT objective (ttl.py:87-108: --deyo_selection False, top-rho selection + avg_entropy) and the PLPD filter with the
+    # reference's DEFAULT --patch_len 6 (224 -> 222 -> 224: both antialiased resizes are live) at the benched size, 64 views / K = 200
+    "b16_n64_k200_tpt": ("ViT-B/16", 64, 200, {"deyo_selection": False}),
+    "b16_n64_k200_plpd": ("ViT-B/16", 64, 200, {"filter_plpd": 1, "plpd_threshold": PLPD_B16_THRESHOLD}),
 }
 
 

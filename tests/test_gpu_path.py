@@ -182,7 +182,7 @@ def test_errors_are_loud():
 
 # ------------------------------------------------------------------ full-size geometries
 @pytest.mark.parametrize("name", ["b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1",
-                                  "l14_n4_k10", "b32_n8_k10", "b16_n8_k10_qkvo", "b16_n64_k200_qkvo", "l14_n64_k200"])
+                                  "l14_n4_k10", "b32_n8_k10", "b16_n8_k10_qkvo", "b16_n64_k200_qkvo", "l14_n64_k200", "b16_n64_k200_tpt"])
 def test_vit_b16_against_reference_goldens(name):
     """BASELINE configs 1-3 shapes (ViT-B/16, r=16; 8 views/K=10, 64 views/K=200 and 64 views/K=1000), config 4 (ViT-L/14, layers
     21-23: 4 views and the full 64 views / K=200), ViT-B/32 and the north_star's q/k/v/out adapter set (8 views and the benched
@@ -388,7 +388,7 @@ def test_r32_128_views_multi_step_invariants():
 # ------------------------------------------------------------------ fp16-operand build (the reference's autocast dtype)
 @pytest.mark.parametrize("name", ["tiny_deyo", "tiny197_deyo", "b16_n8_k10", "b16_n64_k200_ent0", "b16_n64_k200_ent1",
                                   "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "l14_n4_k10", "b32_n8_k10", "b16_n8_k10_qkvo",
-                                  "b16_n64_k200_qkvo", "l14_n64_k200"])
+                                  "b16_n64_k200_qkvo", "l14_n64_k200", "b16_n64_k200_tpt"])
 def test_fp16_operands_meet_the_1e3_tolerance(name):
     """libttl_hip_fp16.so: same kernels with IEEE-half MFMA operands (what torch.cuda.amp.autocast() uses in
     the reference's GPU path, ttl.py:79) and a fixed 2^10 loss scale in the backward (cf. GradScaler,

@@ -3,8 +3,9 @@ episode (ttl_episode_args.plpd; SURVEY §8f-3, round-4 review item 4).
 
   * ttl_plpd_views against the torch chain the reference runs (ttl_amd.deyo.plpd_views: the same einops / torchvision operations
     as deyo.py:118-134 written with view / permute / F.interpolate(antialias=True)), same host RNG draws:
-    'pixel' and 'patch' with image_size % patch_len == 0 (the reference's default 224 / 4) are pure gathers -> BIT-equal;
-    'occ' (a mean) and 'patch' with the two antialiased resizes -> within 2e-6 absolute (summation order);
+    'pixel' and 'patch' with image_size % patch_len == 0 (e.g. 224 / 4) are pure gathers -> BIT-equal;
+    'occ' (a mean) and 'patch' with the two antialiased resizes (the reference's default --patch_len 6: 224 -> 222 -> 224) -> within
+    2e-6 absolute (summation order);
   * ttl_plpd_keep against the reference's formula (deyo.py:137-146);
   * the fused episode with a PLPD stage against the fixtures the reference wrote (tiny_plpd, tiny_plpd_occ, tiny_plpd_pixel,
     tiny_text_plpd): second-stage selection exactly the reference's, PLPD values, weights and adapted logits — on the strict
@@ -27,7 +28,7 @@ def _args(**kw):
 
 
 @pytest.mark.parametrize("aug,S,patch_len", [("pixel", 64, 4), ("patch", 64, 4), ("patch", 224, 4), ("occ", 64, 4), ("patch", 64, 3),
-                                            ("patch", 224, 5), ("patch", 63, 4)])
+                                            ("patch", 224, 5), ("patch", 63, 4), ("patch", 224, 6)])      # (224, 6): the reference's default --patch_len
 @pytest.mark.parametrize("precision", ["fp16"])
 def test_plpd_views_vs_the_torch_chain(aug, S, patch_len, precision):
     from ttl_amd import deyo as D
@@ -107,7 +108,7 @@ def _spec_of(g):
                 column_start=int(g["column_start"]) if "column_start" in g.files else 0)
 
 
-@pytest.mark.parametrize("name", ["tiny_plpd", "tiny_plpd_occ", "tiny_plpd_pixel"])
+@pytest.mark.parametrize("name", ["tiny_plpd", "tiny_plpd_occ", "tiny_plpd_pixel", "b16_n64_k200_plpd"])
 @pytest.mark.parametrize("precision", ["strict", "fp16", "bf16"])
 def test_fused_episode_with_a_plpd_stage_vs_reference(name, precision):
     """ttl_episode with ttl_episode_args.plpd against the fixture the reference wrote with --filter_plpd 1: the first-stage list,

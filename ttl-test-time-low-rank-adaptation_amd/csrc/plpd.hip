@@ -11,7 +11,7 @@
 // torch.randperm(S*S) on the CPU generator) and arrive as int32 device arrays; the kernels are pure byte movement except for the
 // resize, which restates ATen's separable antialiased bilinear (aten/src/ATen/native/cpu/UpSampleKernel.cpp,
 // _compute_indices_min_size_weights_aa + basic_loop_aa_*: horizontal pass, then vertical, fp32 weights normalised per output
-// index).  With image_size % patch_len == 0 (224 / 4, the reference's default) both resizes are the identity and 'patch' is a
+// index).  With image_size % patch_len == 0 (e.g. 224 / 4; the reference's default --patch_len 6 is NOT such a case) both resizes are the identity and 'patch' is a
 // pure gather: bit-identical to the torch chain; otherwise within 1e-6 (summation / contraction order), tests/test_gpu_plpd.py.
 // Every kernel is guarded by the DEVICE-side selection count *n_sel (the host sizes the launch for the count it expects).
 #include "kernels.hpp"

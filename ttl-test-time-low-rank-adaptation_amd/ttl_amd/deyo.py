@@ -121,7 +121,7 @@ def plpd_spec(args):
     """The PLPD arguments of the reference's CLI (ttl.py argparse: --aug_type, --plpd_threshold, --patch_len, --occlusion_size,
     --row_start, --column_start) as the dict TTLEngine.plpd_struct takes."""
     return dict(aug_type=getattr(args, "aug_type", "patch"), threshold=float(getattr(args, "plpd_threshold", 0.2)),
-                patch_len=int(getattr(args, "patch_len", 4)), occlusion_size=int(getattr(args, "occlusion_size", 0) or 0),
+                patch_len=int(getattr(args, "patch_len", 6)), occlusion_size=int(getattr(args, "occlusion_size", 0) or 0),
                 row_start=int(getattr(args, "row_start", 0) or 0), column_start=int(getattr(args, "column_start", 0) or 0))
 
 
