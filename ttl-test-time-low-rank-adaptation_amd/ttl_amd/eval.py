@@ -206,7 +206,8 @@ class SyntheticImages:
 
 
 RESUME_TAG_FIELDS = ("arch", "images", "views", "classes", "rank", "lr", "tta_steps", "selection_p", "filter_ent", "deyo_selection",
-                     "deyo_margin_e0", "reweight_ent", "streams", "precision", "gpu_views", "lora_encoder", "seed")
+                     "deyo_margin_e0", "reweight_ent", "streams", "precision", "gpu_views", "lora_encoder", "seed",
+                     "filter_plpd", "plpd_threshold", "aug_type", "patch_len", "occlusion_size", "row_start", "column_start")
 
 
 def resume_tag(a):
@@ -230,8 +231,17 @@ def main():
     ap.add_argument("--deyo_selection", default=True)
     ap.add_argument("--deyo_margin_e0", type=float, default=0.4)
     ap.add_argument("--reweight_ent", type=int, default=1)
+    # the PLPD filter of DeYO, with the reference's CLI names and defaults (ttl.py:408-422)
+    ap.add_argument("--filter_plpd", type=int, default=0)
+    ap.add_argument("--reweight_plpd", type=int, default=0)
+    ap.add_argument("--plpd_threshold", type=float, default=0.2)
+    ap.add_argument("--aug_type", default="patch", choices=["patch", "pixel", "occ"])
+    ap.add_argument("--patch_len", type=int, default=6)
+    ap.add_argument("--occlusion_size", type=int, default=112)
+    ap.add_argument("--row_start", type=int, default=56)
+    ap.add_argument("--column_start", type=int, default=56)
     ap.add_argument("--streams", type=int, default=3)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "strict"])
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic data and of the GPU view generator's crop boxes")
