@@ -38,6 +38,13 @@
 //     episode 2.88 vs 2.76 ms in situ, 277 vs 285 images/s — the epilogue is bound by lines touched, not by store instructions;
 //     whole 128-B lines per row stay.
 //   * starting half of the blocks 1-4 us late (de-synchronising the epilogue store bursts): the delay is simply exposed.
+//   * (round 5) what the vendor library runs on these shapes: rocprofv3 of torch.matmul shows hipBLASLt serving N >= 2304, K = 768 with
+//     MT256x256x64 on FOUR waves (128 x 128 per wave, accumulators in AGPRs, global -> VGPR prefetch two K-tiles deep, stream-K) at
+//     46.5 us on the QKV shape against 52-54 us here, i.e. 15-18 % less CU-time per launch — and with three episodes in flight CU-time
+//     per tile is what a launch costs, not its round count (a grid of 224 blocks: +23 % GEMM time one at a time, same images/s).
+//     A first HIP-source cut of that design (256 threads, compiler-scheduled ds_read / ds_write / MFMA, one K-tile of prefetch
+//     registers) measured 106 us on the QKV shape and 146 us on fc1: the shape only pays with an assembly-grade schedule
+//     (profiles/r05_experiments.txt r05i-r05l).  The one GEMM lever left on the table.
 #include <stdlib.h>
 
 #include <atomic>
@@ -509,7 +516,6 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
 }
 
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
-    if (gemm_huge_applicable(epi, a)) return launch_gemm_huge(epi, a, s);
     // Tile height (TTL_GEMM_BIG_MT), ring depth, tile order, resident blocks: tuned in situ, see DESIGN.md §3.1
     static const int mt_env = env_int("TTL_GEMM_BIG_MT", 5);
     static const int st_env = env_int("TTL_GEMM_BIG_STAGES", 0);

@@ -80,9 +80,6 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a);
 // true iff launch_gemm(epi, a) runs on the big-M kernel (a.padded set as the caller will set it): the only path with GemmArgs::hm_T
 bool gemm_takes_big(GemmEpi epi, const GemmArgs& a);
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s);
-// gemm_huge.hip (experiment, TTL_GEMM_HUGE=1): 256 x 256 x 64 tiles on four waves with 128 x 128 wave tiles, for the wide short-K launches
-bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a);
-hipError_t launch_gemm_huge(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 hipError_t launch_cast_f32_op(const float* src, op_t* dst, size_t n, hipStream_t s);
