@@ -8,4 +8,4 @@ run() { env $1 python3 bench.py $Q 2>/dev/null | python3 -c "
 import sys, json
 d = [json.loads(l) for l in sys.stdin if l.startswith('{')][-1]
 print('%-34s %7.2f images/s (%.2f-%.2f)  gemm one-at-a-time %.3f ms' % ('$1', d['value'], d['value_min'], d['value_max'], d['roofline']['class_ms_per_image']['gemm']))"; }
-{ for v in TTL_NOP=1 TTL_GEMM_BIG_MT=7 TTL_GEMM_BIG_MT=8 TTL_NOP=1 TTL_GEMM_BIG_STAGES=2 TTL_GEMM_BIG_MT=8 TTL_GEMM_BIG_MT=7 TTL_NOP=1; do run $v; done; } | tee gpurun_out/r05_fp16/mt_sweep.txt
+{ for v in ${SWEEP:-TTL_NOP=1 TTL_GEMM_BIG_MT=7 TTL_GEMM_BIG_MT=8 TTL_NOP=1 TTL_GEMM_BIG_STAGES=2 TTL_GEMM_BIG_MT=8 TTL_GEMM_BIG_MT=7 TTL_NOP=1}; do run $v; done; } | tee -a gpurun_out/r05_fp16/mt_sweep.txt

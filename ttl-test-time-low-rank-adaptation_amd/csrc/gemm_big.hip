@@ -524,6 +524,9 @@ hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
     const int cus = device_cu_count();
     if (!cus) return hipErrorInvalidDevice;
     int mt = mt_env;
+    // TTL_GEMM_BIG_MT_WIDE (experiment r05m): another tile height for the wide, short-K launches only (QKV, fc1, MLP dgrad is separate)
+    static const int mt_wide = env_int("TTL_GEMM_BIG_MT_WIDE", 0);
+    if (mt_wide && a.N >= 2304 && a.K <= 1024) mt = mt_wide;
     if ((size_t)((a.M + 32 * mt - 1) / (32 * mt)) * 32 * mt > (size_t)a.padded) mt = 5;   // a.padded = rows every output buffer has
     if ((size_t)((a.M + 159) / 160) * 160 > (size_t)a.padded) return hipErrorInvalidValue;
     const int stages = (mt == 5) ? (st_env ? st_env : 3) : 2;
