@@ -295,6 +295,13 @@ int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ld
  * output / resid buffer really has: >= round_up(M, 1280) selects the unguarded big-M kernels the episode uses, 0 the guarded ones. */
 int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epi,
                     const float* bias, const float* resid, int ldr, int rows_allocated, void* stream);
+/* The two fused forms the episode's wide projections use (csrc/gemm_huge.hip, csrc/gemm_big.hip), operand-dtype outputs:
+ *   hm_T > 0 (q/k/v, modeling_clip.py:309-311): C is written head-major — row m = view * hm_T + t, column plane * D + head * 64 + d
+ *            (D = N / 3) goes to C[((view * 3 + plane) * D + head * 64) * hm_T + t * 64 + d]; C2 must be NULL;
+ *   hm_T == 0 (fc1, modeling_clip.py:346-348): C = quick_gelu(product + bias) and, if C2 != NULL, C2 = product + bias.
+ * rows_allocated as ttl_gemm_nt_epi.  TTL_EINVAL when the shape does not run on a big-M kernel (M < 1024, N % 256, ...). */
+int ttl_gemm_nt_fused(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2, int M, int N, int K,
+                      const float* bias, int hm_T, int rows_allocated, void* stream);
 /* y = LayerNorm(x) over the last dim (fp32 in, fp32 out, optional mean/rstd [rows]). */
 int ttl_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                       float* rstd, int rows, int dim, float eps, void* stream);

@@ -325,6 +325,27 @@ def test_gemm_big_tiles_with_fused_epilogues(lib, prec, M, N, K, epi):
         assert (c[top:].float() == 7.0).all()
 
 
+def test_gemm_wide_fused_forms(lib, prec):
+    """q/k/v head-major (modeling_clip.py:309-311 written as [view][plane][head][T][64]) and fc1 with both outputs (quick_gelu and
+    the pre-activation the backward reads) through ttl_gemm_nt_fused — the forms no other kernel-level entry reaches — on both
+    kernels that have them: in this process the default split (q/k/v on gemm_huge.hip's 256 x 256 four-wave tiles, fc1 on
+    gemm_big.hip's 160 x 256), in child processes TTL_GEMM_HUGE=0 (everything on gemm_big.hip) and =1 (everything on gemm_huge.hip).
+    The strict build has neither form (row-major q/k/v, its own GEMM): the entry must say so."""
+    import os, subprocess, sys
+    import gemm_fused_check as G
+    if prec == "strict":
+        a = torch.zeros(1280, 768, device="cuda")
+        c = torch.zeros(1280 * 2304, device="cuda")
+        assert lib.ttl_gemm_nt_fused(P(a), 768, P(a), 768, P(c), 2304, None, 0, 1280, 2304, 768, None, 197, 1280, S()) != 0
+        return
+    for shp in G.SHAPES:
+        G.check(lib, prec, *shp)
+    for mode in ("0", "1"):
+        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode), capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0 and f"ok {prec} mode {mode}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_gradscaler_known_answers(lib, prec):
     """ttl_scaler_config / ttl_scaler_unscale / ttl_optimizer_step against the reference's own objects — torch.amp.GradScaler(
     init_scale=1000) around torch.optim.AdamW — over 9 updates with an inf and a nan injected (fixture written by

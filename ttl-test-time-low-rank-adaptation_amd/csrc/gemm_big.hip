@@ -516,6 +516,7 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
 }
 
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
+    if (gemm_huge_applicable(epi, a)) return launch_gemm_huge(epi, a, s);     // q/k/v, fc1: 256 x 256 tiles on four waves (gemm_huge.hip)
     // Tile height (TTL_GEMM_BIG_MT), ring depth, tile order, resident blocks: tuned in situ, see DESIGN.md §3.1
     static const int mt_env = env_int("TTL_GEMM_BIG_MT", 5);
     static const int st_env = env_int("TTL_GEMM_BIG_STAGES", 0);

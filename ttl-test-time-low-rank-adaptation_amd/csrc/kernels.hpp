@@ -80,6 +80,10 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a);
 // true iff launch_gemm(epi, a) runs on the big-M kernel (a.padded set as the caller will set it): the only path with GemmArgs::hm_T
 bool gemm_takes_big(GemmEpi epi, const GemmArgs& a);
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+// gemm_huge.hip: 256 x 256 tiles on four waves for the wide, short-K big-M launches (q/k/v, fc1); launch_gemm_big hands these over
+// (so gemm_takes_big still answers for them; TTL_GEMM_HUGE=0: everything stays on gemm_big.hip)
+bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a);
+hipError_t launch_gemm_huge(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 hipError_t launch_cast_f32_op(const float* src, op_t* dst, size_t n, hipStream_t s);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ttl_episode": (_I, [_P, C.POINTER(ttl_episode_args), _P]),
     "ttl_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ttl_gemm_nt_epi": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
+    "ttl_gemm_nt_fused": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "ttl_layernorm_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "ttl_cast_f32_operand": (_I, [_P, _P, _Z, _P]),
     "ttl_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
