@@ -582,7 +582,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach1, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_unit": "HBM-side bytes per GEMM launch",
                 "algorithmic_bytes_per_launch": round(alg_bytes),
-                "kernel": "gemm_big_kernel<5,3,EPI> (160x256x64 tiles, 8 waves, one persistent block per CU) + gemm_kernel<160,2,2,2,EPI> "
+                "kernel": "gemm_big_kernel<5,3,EPI> (160x256x64 tiles, 8 waves, one persistent block per CU) + gemm_huge_kernel<EPI> (256x256x64, "
+                          "4 waves, LDS-DMA rings) for the q/k/v projection + gemm_kernel<160,2,2,2,EPI> "
                           "for the MLP-dgrad / patch-embed epilogues: every big-M (M >= 1024) GEMM launch of an episode; the small-M "
                           "launches (1-view inference, CLS-row GEMMs of the last layer) are class gemm_small_m",
                 "regime": "one episode at a time (kernel alone on the chip; HIP events on the launch stream)",

@@ -269,14 +269,16 @@ def test_numa_pinning_skips_kfd_nodes_the_container_may_not_read(tmp_path):
 
 def test_resume_tag_names_every_result_affecting_argument():
     """round-3 advisor (eval.py:245): a progress file written under another --precision / --tta_steps / --lr / selection / margin /
-    reweighting / seed must not be resumed from."""
+    reweighting / seed — or another PLPD filter setting (deyo.py:115-151) — must not be resumed from."""
     import argparse
     from ttl_amd.eval import resume_tag, RESUME_TAG_FIELDS
     a = argparse.Namespace(arch="ViT-B/16", images=8, views=64, classes=200, rank=16, lr=5e-3, tta_steps=1, selection_p=0.1, filter_ent=0,
-                           deyo_selection=True, deyo_margin_e0=0.4, reweight_ent=1, streams=3, precision="bf16", gpu_views=0, lora_encoder="image", seed=0)
+                           deyo_selection=True, deyo_margin_e0=0.4, reweight_ent=1, streams=3, precision="bf16", gpu_views=0, lora_encoder="image", seed=0,
+                           filter_plpd=0, plpd_threshold=0.2, aug_type="patch", patch_len=6, occlusion_size=112, row_start=56, column_start=56)
     assert set(RESUME_TAG_FIELDS) == set(vars(a))
     base = resume_tag(a)
     changed = dict(arch="ViT-L/14", images=9, views=32, classes=10, rank=32, lr=1e-3, tta_steps=2, selection_p=0.2, filter_ent=1, deyo_selection=False,
-                   deyo_margin_e0=0.5, reweight_ent=0, streams=2, precision="fp16", gpu_views=1, lora_encoder="text", seed=1)
+                   deyo_margin_e0=0.5, reweight_ent=0, streams=2, precision="fp16", gpu_views=1, lora_encoder="text", seed=1,
+                   filter_plpd=1, plpd_threshold=0.3, aug_type="occ", patch_len=4, occlusion_size=64, row_start=0, column_start=8)
     for k, v in changed.items():
         assert resume_tag(argparse.Namespace(**{**vars(a), k: v})) != base, k

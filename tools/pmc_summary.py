@@ -62,7 +62,7 @@ def main(argv):
             lines.append("    -> " + "; ".join(der))
     open(out_txt, "w").write("\n".join(lines) + "\n")
     if out_json:
-        big = {k: v for k, v in traffic.items() if ("gemm_big_kernel" in k or "gemm_kernel<160" in k) and v["read_bytes_per_launch"] is not None
+        big = {k: v for k, v in traffic.items() if ("gemm_big_kernel" in k or "gemm_huge_kernel" in k or "gemm_kernel<160" in k) and v["read_bytes_per_launch"] is not None
                and v["write_bytes_per_launch"] is not None}
         n = sum(v["launches"] for v in big.values())
         tot = sum(v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in big.values())

@@ -33,7 +33,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd", "csrc")
-FILES = ["gemm_big.hip", "gemm.hip", "attention.hip", "lora.hip", "head_loss.hip", "elementwise.hip", "views.hip"]
+FILES = ["gemm_big.hip", "gemm_huge.hip", "gemm.hip", "attention.hip", "lora.hip", "head_loss.hip", "elementwise.hip", "views.hip"]
 BUILDS = {"bf16": [], "fp16": ["-DTTL_OPERAND_FP16"]}
 WINDOW = 4
 

@@ -43,8 +43,9 @@
 //     46.5 us on the QKV shape against 52-54 us here, i.e. 15-18 % less CU-time per launch — and with three episodes in flight CU-time
 //     per tile is what a launch costs, not its round count (a grid of 224 blocks: +23 % GEMM time one at a time, same images/s).
 //     A first HIP-source cut of that design (256 threads, compiler-scheduled ds_read / ds_write / MFMA, one K-tile of prefetch
-//     registers) measured 106 us on the QKV shape and 146 us on fc1: the shape only pays with an assembly-grade schedule
-//     (profiles/r05_experiments.txt r05i-r05l).  The one GEMM lever left on the table.
+//     registers) measured 106 us on the QKV shape; hand-pipelined it reached 57 us, and with LDS-DMA rings instead of staging registers
+//     49.4 us (this kernel 52.9, library 48.2 on that lease): that third cut is gemm_huge.hip and takes the q/k/v launches
+//     (+1.1 % images/s in situ; fc1 gains nothing there and stays here) — profiles/r05_experiments.txt r05i-r05n.
 #include <stdlib.h>
 
 #include <atomic>
