@@ -25,8 +25,19 @@ def huge_mode():
     return int(os.environ.get("TTL_GEMM_HUGE", "2"))
 
 
+def takes_huge(M, N, T):
+    """csrc/gemm_huge.hip gemm_huge_applicable, for the shapes of this file: the launch family is switched on and the launch has
+    256 x 256 tiles for TTL_GEMM_HUGE_MIN_FILL (default 85) percent of the CUs."""
+    mode = huge_mode()
+    if not (mode == 1 or (mode == 2 and T > 0) or (mode == 3 and T == 0)):
+        return False
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (M + 255) // 256 * (N // 256)
+    return tiles * 100 >= cus * int(os.environ.get("TTL_GEMM_HUGE_MIN_FILL", "85"))
+
+
 def check(lib, prec, M, N, K, T):
-    huge_on = huge_mode() == 1 or (huge_mode() == 2 and T > 0) or (huge_mode() == 3 and T == 0)
+    huge_on = takes_huge(M, N, T)
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cpu").manual_seed(M + N + K + T)
@@ -69,4 +80,4 @@ if __name__ == "__main__":
     lib = _lib.load(prec)
     for shp in SHAPES:
         check(lib, prec, *shp)
-    print("ok", prec, "mode", huge_mode(), len(SHAPES))
+    print("ok", prec, "mode", huge_mode(), len(SHAPES), "on gemm_huge:", sum(takes_huge(M, N, T) for M, N, K, T in SHAPES))

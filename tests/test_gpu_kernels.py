@@ -328,8 +328,9 @@ def test_gemm_big_tiles_with_fused_epilogues(lib, prec, M, N, K, epi):
 def test_gemm_wide_fused_forms(lib, prec):
     """q/k/v head-major (modeling_clip.py:309-311 written as [view][plane][head][T][64]) and fc1 with both outputs (quick_gelu and
     the pre-activation the backward reads) through ttl_gemm_nt_fused — the forms no other kernel-level entry reaches — on both
-    kernels that have them: in this process the default split (q/k/v on gemm_huge.hip's 256 x 256 four-wave tiles, fc1 on
-    gemm_big.hip's 160 x 256), in child processes TTL_GEMM_HUGE=0 (everything on gemm_big.hip) and =1 (everything on gemm_huge.hip).
+    kernels that have them: in this process the default split (q/k/v launches with tiles for most of the CUs on gemm_huge.hip's 256 x 256
+    four-wave tiles, everything else on gemm_big.hip's 160 x 256), in child processes TTL_GEMM_HUGE=0 (everything on gemm_big.hip)
+    and =1 with the round-fill rule off (everything on gemm_huge.hip).
     The strict build has neither form (row-major q/k/v, its own GEMM): the entry must say so."""
     import os, subprocess, sys
     import gemm_fused_check as G
@@ -340,10 +341,11 @@ def test_gemm_wide_fused_forms(lib, prec):
         return
     for shp in G.SHAPES:
         G.check(lib, prec, *shp)
-    for mode in ("0", "1"):
-        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode), capture_output=True, text=True,
-                             timeout=600)
+    for mode in ("0", "1"):      # (mode 1 with the round-fill rule off: every shape on gemm_huge.hip)
+        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0"),
+                             capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and f"ok {prec} mode {mode}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        assert f"on gemm_huge: {len(G.SHAPES) if mode == '1' else 0}" in out.stdout, out.stdout[-500:]
 
 
 def test_gradscaler_known_answers(lib, prec):

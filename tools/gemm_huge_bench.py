@@ -4,8 +4,8 @@ csrc/gemm_big.hip (160 x 256, eight waves) and the vendor library, on one lease.
 
     python tools/gemm_huge_bench.py [fp16|bf16]
 
-TTL_GEMM_HUGE is read once per process, so each setting runs in a child process (TTL_GEMM_HUGE=1: both forms on gemm_huge.hip,
-0: both on gemm_big.hip); six operand sets are rotated so that no launch finds its inputs in the caches."""
+TTL_GEMM_HUGE is read once per process, so each setting runs in a child process (TTL_GEMM_HUGE=1 with the round-fill rule off: every
+shape on gemm_huge.hip, 0: every shape on gemm_big.hip); six operand sets are rotated so that no launch finds its inputs in the caches."""
 import ctypes as C
 import os
 import statistics
@@ -65,6 +65,6 @@ if __name__ == "__main__":
     prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
     for mode, label in (("1", "gemm_huge.hip (256 x 256, four waves)"), ("0", "gemm_big.hip (160 x 256, eight waves)"), ("1", "gemm_huge.hip again")):
         print(f"---- TTL_GEMM_HUGE={mode}: {label}   [{prec}]", flush=True)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), prec, "--child"], env=dict(os.environ, TTL_GEMM_HUGE=mode))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), prec, "--child"], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0"))
         if r.returncode:
             sys.exit(r.returncode)

@@ -25,6 +25,7 @@
 //     accumulators' initial value; persistent tile loop, the next tile's bias and first K-tiles requested before the last 16 MFMAs
 //     and the stores of the current one
 //   * stores through buffer descriptors: rows >= M are dropped by the range check (no padding requirement on the outputs)
+//   * taken only when the launch has tiles for >= 85 % of the CUs (gemm_huge_applicable)
 // History of the design (first cut with compiler-scheduled register staging 106 us, hand-pipelined register staging 57-60 us, all-DMA
 // with bunched requests 56 us): profiles/r05_experiments.txt r05l, r05n.
 #include <stdlib.h>
@@ -260,6 +261,15 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     if ((mode == 2 && epi != EPI_OP) || (mode == 3 && epi != EPI_GELU)) return false;
     if (a.M < 1024 || a.N < 2304 || a.N % BN || a.K % BK || a.K / BK < 3 || a.K > 1024) return false;
     if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
+    // The launch has to fill (most of) one round of 256 x 256 tiles over the CUs: below that the 160 x 256 kernel's smaller tiles keep
+    // more CUs busy (8 views: 63 tiles here, 90 there: 1157 vs 1168 images/s).  Partial LATER rounds are not held against it: ViT-L/14's
+    // 780 tiles (76 % of four rounds) are 5.7 % slower one at a time (107.9 vs 102.1 us) and still +0.8 % images/s with three episodes
+    // in flight, where a launch costs tiles x time per tile (tools/r05_huge_fill_ab.sh).  TTL_GEMM_HUGE_MIN_FILL: percent of one round.
+    static const int min_fill = [] { const char* v = getenv("TTL_GEMM_HUGE_MIN_FILL"); return v ? atoi(v) : 85; }();
+    const long cus = device_cu_count();
+    if (cus <= 0) return false;
+    const long tiles = (long)((a.M + BM - 1) / BM) * (a.N / BN);
+    if (tiles * 100 < cus * min_fill) return false;
     // 32-bit buffer offsets: every operand / output extent stays below 2 GiB
     const size_t lim = (size_t)1 << 31;
     if ((size_t)a.M * a.lda * sizeof(op_t) >= lim || (size_t)a.N * a.ldb * sizeof(op_t) >= lim) return false;
