@@ -51,6 +51,11 @@ def parse_args():
                          "rank shares the host or when the warm-up shows the enqueue loop taking > 50 %% of a step; decided ONCE for all legs")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps images each; value = the median block.  When a block "
                     "is shorter than 0.25 s the count is raised until the timed blocks cover 1.5 s (at most 25)")
+    ap.add_argument("--selection", default="all", choices=["all", "topk", "tpt"],
+                    help="which views carry the loss: all = the reference's default (--filter_ent 0: every view, deyo.py:107; the BASELINE "
+                         "configuration), topk = --filter_ent 1 (deyo.py:105: the int(0.1 * views) lowest-entropy views), tpt = the "
+                         "averaged-entropy objective over the same top-k (ttl.py:87-108).  With a top-k selection the backward runs on the "
+                         "selected views only (csrc/api.hip backward_impl)")
     ap.add_argument("--lora-targets", default="qv", help="projections that carry an adapter: qv (the reference's LoraConfig, "
                     "clip/custom_clip.py:586), qkvo (BASELINE.json north_star), or a comma list of q_proj,k_proj,v_proj,out_proj")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores of its GPU's NUMA node")
@@ -361,6 +366,9 @@ def main():
     if overrides and not a.variant_lib:
         raise SystemExit(f"{', '.join(overrides)} would swap the library under the bench: pass --variant-lib if that is intended")
     self_spawn(a)
+    # episode keyword arguments of the chosen selection (engine.TTLEngine.episode: mode 1 = TTL_SEL_TOPK)
+    sel_kw = {} if a.selection == "all" else dict(mode=1, rho=0.1, **({"objective": "tpt"} if a.selection == "tpt" else {}))
+    sel_text = {"all": "", "topk": "top-k selection (--filter_ent 1, 10 % of the views), ", "tpt": "TPT objective over the top 10 % of the views, "}[a.selection]
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -456,7 +464,7 @@ def main():
         -> (wall s incl. the closing barrier, max over ranks; s spent in submit(); s until this rank alone had finished)"""
         t0 = time.perf_counter()
         for i in shard.indices(world * n_items):
-            pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, want_output=False, n_updates=a.updates)
+            pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, want_output=False, n_updates=a.updates, **sel_kw)
         t_enq = time.perf_counter() - t0
         t_local = t_enq + fence(pipe)
         dt = time.perf_counter() - t0
@@ -562,14 +570,14 @@ def main():
 
         def run_all():
             for i in range(nprof):
-                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], persistent_input=True, want_output=False, n_updates=a.updates)
+                pipe.submit(pool[i % a.pool], target=labels[i % a.pool], persistent_input=True, want_output=False, n_updates=a.updates, **sel_kw)
             pipe.synchronize()
 
         def run_one():
             sl = pipe.slots[0]
             for i in range(nprof):
                 with torch.cuda.stream(sl["stream"]):
-                    eng.episode(pool[i % a.pool], sl["snap"], sl["m"], sl["v"], n_updates=a.updates)
+                    eng.episode(pool[i % a.pool], sl["snap"], sl["m"], sl["v"], n_updates=a.updates, **sel_kw)
             sl["stream"].synchronize()
         graph_mode, pipe.use_graph = pipe.use_graph, False     # per-launch events need real launches, not a graph replay
         ms, cnt, gflops = profiled(run_all, [sl["eng"] for sl in pipe.slots])
@@ -658,9 +666,9 @@ def main():
             "protocol": {"steps": a.steps, "warmup": a.warmup, "repeats": n["repeats"], "hip_graph": use_graph, "hip_graph_reason": why,
                          "legs": legs, "interleaved_blocks": len(legs) > 1, "variant_lib_env": overrides},
             "config": {"workload": f"{cfg.name} r={cfg.rank}, adapters on {tg}, {a.views} views, {a.updates} TTA step, K={a.classes} "
-                                   f"(ImageNet-A shape), layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
+                                   f"(ImageNet-A shape), {sel_text}layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
                                    f"1-view inference; views pre-staged in HBM; {a.steps} images/rank per timed block",
-                       "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates,
+                       "arch": cfg.name, "views": a.views, "classes": a.classes, "rank": cfg.rank, "updates": a.updates, "selection": a.selection,
                        "lora_targets": list(targets), "streams_per_gpu": a.streams, "hip_graph": use_graph,
                        "hip_graph_reason": why, "hip_graph_per_rank": graph_per_rank, "cpu_pinning": pin, "rccl_version": rccl,
                        "backend": a.backend if world > 1 else None,

@@ -157,6 +157,12 @@ int ttl_ctx_tpt_select_loss(ttl_ctx* ctx, const float* logits, int n_views, int 
  * post-LN -> layers layer_hi..layer_lo, writing dA/dB of q_proj and v_proj into the bound grads
  * buffer (overwritten, i.e. optimizer.zero_grad() + backward, deyo.py:185-186). */
 int ttl_vit_backward_lora(ttl_ctx* ctx, const float* dlogits, int n_views, void* stream);
+/* The same backward when the caller knows that dlogits is zero outside the n_selected views idx lists (device memory, distinct view
+ * numbers < n_views) — the list a top-k selection produced: deyo.py:105 `argsort(entropys)[:int(N * selection_p)]` (--filter_ent 1),
+ * ttl.py:52 select_confident_samples (TPT).  Rows of the other views contribute exactly nothing to any LoRA gradient, so the backward
+ * runs on the listed views only (their saved activations are packed first; 6 of 64 views at the reference's selection_p = 0.1).
+ * Falls back to the full backward when n_selected is 0, equals n_views or exceeds max_views / 4.  ttl_episode applies the same rule. */
+int ttl_vit_backward_lora_selected(ttl_ctx* ctx, const float* dlogits, int n_views, const int64_t* idx, int n_selected, void* stream);
 
 /* torch.optim.AdamW.step over one flat buffer (ttl.py:218; deyo.py:187).  `step` is the 1-based
  * step count of this update.  If `n_selected` (device int32, may be NULL) is 0 the update is

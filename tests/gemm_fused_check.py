@@ -36,21 +36,24 @@ def takes_huge(M, N, T):
     return tiles * 100 >= cus * int(os.environ.get("TTL_GEMM_HUGE_MIN_FILL", "85"))
 
 
-def check(lib, prec, M, N, K, T):
+def check(lib, prec, M, N, K, T, lda_pad=0, with_bias=True):
+    """lda_pad: extra columns in the A buffer behind the K the product reads (the episode's K-extended operand buffers); with_bias=False:
+    null bias pointer."""
     huge_on = takes_huge(M, N, T)
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cpu").manual_seed(M + N + K + T)
-    a = torch.randn(M, K, generator=g).to(TDT[prec]).cuda()
+    abuf = torch.randn(M, K + lda_pad, generator=g).to(TDT[prec]).cuda()
+    a = abuf[:, :K]
     b = (torch.randn(N, K, generator=g) * 0.05).to(TDT[prec]).cuda()
-    bias = torch.randn(N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda() if with_bias else None
     Mp = (M + 1279) // 1280 * 1280 + 320
     c = torch.full((Mp, N), 7.0, device="cuda", dtype=TDT[prec])
     c2 = None if T else torch.full((Mp, N), 7.0, device="cuda", dtype=TDT[prec])
-    rc = lib.ttl_gemm_nt_fused(P(a), K, P(b), K, P(c), N, P(c2), N, M, N, K, P(bias), T, Mp, stream)
+    rc = lib.ttl_gemm_nt_fused(P(abuf), K + lda_pad, P(b), K, P(c), N, P(c2), N, M, N, K, P(bias), T, Mp, stream)
     assert rc == 0, (rc, lib.ttl_last_error())
     torch.cuda.synchronize()
-    want = a.float() @ b.float().t() + bias
+    want = a.float() @ b.float().t() + (bias if with_bias else 0.0)
     tol = OUT_TOL[prec]
     if T:
         views, D = M // T, N // 3
@@ -80,4 +83,7 @@ if __name__ == "__main__":
     lib = _lib.load(prec)
     for shp in SHAPES:
         check(lib, prec, *shp)
+    check(lib, prec, 12608, 2304, 768, 197, lda_pad=64)
+    check(lib, prec, 12608, 2304, 768, 197, with_bias=False)
+    check(lib, prec, 12608, 3072, 768, 0, lda_pad=64, with_bias=False)
     print("ok", prec, "mode", huge_mode(), len(SHAPES), "on gemm_huge:", sum(takes_huge(M, N, T) for M, N, K, T in SHAPES))

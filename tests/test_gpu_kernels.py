@@ -341,6 +341,8 @@ def test_gemm_wide_fused_forms(lib, prec):
         return
     for shp in G.SHAPES:
         G.check(lib, prec, *shp)
+    G.check(lib, prec, 12608, 2304, 768, 197, lda_pad=64)            # A as the first K columns of a wider buffer
+    G.check(lib, prec, 12608, 2304, 768, 197, with_bias=False)       # null bias
     for mode in ("0", "1"):      # (mode 1 with the round-fill rule off: every shape on gemm_huge.hip)
         out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0"),
                              capture_output=True, text=True, timeout=600)

@@ -128,6 +128,14 @@ struct ttl_ctx {
     // GradScaler state (device) and policy (host): ttl.py:222, deyo.py:186-188
     ScalerState sc{nullptr, nullptr};
     int sc_dynamic = 0; float sc_growth = 2.f, sc_backoff = 0.5f; int sc_interval = 2000;
+    // Backward on the selected views only (top-k selections: deyo.py:105 filter_ent, ttl.py:52 TPT; TTL_BWD_COMPACT=0: off).  The loss
+    // gradient is zero outside the int(n * rho) selected views, so their rows contribute nothing to any LoRA gradient: the saved
+    // activations of the selected views are packed into these buffers (room for sel_cap views, sel_rows rows) and the same backward
+    // runs with n = n_sel.  Image tower only.
+    struct SelBuf { float *h_in, *h_mid, *lse, *mu1, *rs1, *mu2, *rs2; op_t *x1ext, *qkv, *attn, *u; };
+    int sel_cap = 0, sel_rows = 0, cur_padded = 0;
+    std::vector<SelBuf> selb;                  // one per saved layer (layer_lo .. L-1)
+    float *sel_mean = nullptr, *sel_rstd = nullptr, *sel_y = nullptr, *sel_f = nullptr, *sel_h = nullptr, *sel_dz = nullptr;
     bool saved = false; int saved_n = 0; int stream_views = 0;
     // profiling
     bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_flops_all = 0, gemm_flops_all_last = 0, gemm_bytes = 0, gemm_bytes_last = 0;
@@ -237,7 +245,8 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     // token-row buffers ([n*T, .]) have Mmax = round_up(max_views*T, 1280) rows: whole row tiles may be stored unguarded.
     // The compact [n, .] buffers of the pooled last layer / CLS-only top-layer backward have exactly max_views rows:
     // guarded kernels, whatever n is.
-    a.padded = (a0.M > c->c.max_views) ? c->Mmax : 0;
+    // (a backward on the packed views reads saved tensors that have sel_rows rows; its outputs are the full-size scratch buffers)
+    a.padded = (a0.M > c->c.max_views) ? (c->cur_padded ? c->cur_padded : c->Mmax) : 0;
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
     if (c->prof) c->gemm_flops_all += 2.0 * a.M * a.N * a.K;
     if (c->prof && big) {
@@ -381,6 +390,27 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
     ALLOC(c->dcls, N * D, false); ALLOC(c->dxc, N * D, false); ALLOC(c->dhmc, N * D, false);
     ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * c->ldh, true); ALLOC(c->doc, N * D, false);
     ALLOC(c->att_g, N * (D + 64), true);
+    {
+        const char* v = getenv("TTL_BWD_COMPACT");
+        const int cap = (int)N / 4;          // top-k selections keep 10 % of the views (ttl.py:376); a quarter of them fit
+        if ((v ? atoi(v) != 0 : 1) && !c->text && cap >= 1 && c->nS > 0) {
+            c->sel_cap = cap;
+            c->sel_rows = round_up(cap * (int)T, 1280);
+            const size_t Ms = (size_t)c->sel_rows;
+            c->selb.resize(c->nS);
+            for (int i = 0; i < c->nS; ++i) {
+                ttl_ctx::SelBuf& b = c->selb[i];
+                const Layer& l = c->layers[k->layer_lo + i];
+                ALLOC(b.h_in, Ms * D, true); ALLOC(b.h_mid, Ms * D, true); ALLOC(b.x1ext, Ms * c->ldx, true);
+                ALLOC(b.qkv, (Ms + T) * 3 * D, true); ALLOC(b.attn, Ms * l.ldat, true); ALLOC(b.u, Ms * F, true);
+                ALLOC(b.lse, (size_t)cap * H * T, true);
+                ALLOC(b.mu1, Ms, true); ALLOC(b.rs1, Ms, true); ALLOC(b.mu2, Ms, true); ALLOC(b.rs2, Ms, true);
+            }
+            ALLOC(c->sel_mean, cap, true); ALLOC(c->sel_rstd, cap, true); ALLOC(c->sel_y, (size_t)cap * D, true);
+            ALLOC(c->sel_f, (size_t)cap * E, true); ALLOC(c->sel_h, (size_t)cap * D, true);
+            ALLOC(c->sel_dz, (size_t)cap * k->max_classes, true);
+        }
+    }
     ALLOC(c->wg_partial, (size_t)lora_wgrad_chunks((int)M) * 2 * c->ntg * r * D, false);
     c->gemm_ws_bytes = (size_t)8 << 20;
     ALLOC(c->gemm_ws, c->gemm_ws_bytes / sizeof(float), false);
@@ -963,20 +993,80 @@ int ttl_ctx_tpt_select_loss(ttl_ctx* c, const float* logits, int N, int K, doubl
 
 // ------------------------------------------------------------------------------ backward
 // inf_cleared: the caller's loss launch has already zeroed found_inf on this stream (the fused episode: deyo_select_grad_kernel)
-static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, bool inf_cleared = false) {
+// How many views a top-k selection of n keeps, if the backward may restrict itself to them (0: run it on all n views).
+static int selected_views(const ttl_ctx* c, int n, int mode, double rho) {
+    if (!c->sel_cap || c->text || mode != TTL_SEL_TOPK) return 0;
+    const int k = (int)((double)n * rho);     // Python: int(batch_entropy.size()[0] * top), ttl.py:52 / deyo.py:105 (launch_entropy_loss)
+    return (k >= 1 && k < n && k <= c->sel_cap) ? k : 0;
+}
+
+// Pack what the backward reads of views sel_idx[0 .. n_sel) (device list) into the context's SelBuf set: one launch.
+static int pack_selected_views(ttl_ctx* c, const float* dlogits, int n, const long long* sel_idx, int n_sel, hipStream_t s) {
+    const size_t D = c->D, F = c->F, T = c->T, H = c->H, E = c->E, K = c->K;
+    static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
+    GatherTable t = {};
+    hipError_t err = hipSuccess;
+    Prof p(c, 3, s);
+    auto flush = [&]() { if (t.n && err == hipSuccess) err = launch_gather_view_blocks(t, sel_idx, n_sel, s); t.n = 0; };
+    auto add = [&](const void* src, void* dst, size_t stride, size_t block) {
+        if (t.n == GATHER_MAX) flush();          // (more saved layers than one table holds: --layer_range from 0)
+        t.e[t.n++] = {src, dst, stride, block};
+    };
+    for (int i = 0; i < c->nS; ++i) {
+        const Layer& l = c->layers[c->c.layer_lo + i];
+        const ttl_ctx::SelBuf& b = c->selb[i];
+        const bool top = (c->c.layer_lo + i == c->L - 1);
+        const bool first = (i == 0);
+        const size_t qkvb = 3 * D * T * sizeof(op_t);                          // both layouts keep a view's q/k/v in one block
+        add(l.qkv, b.qkv, qkvb, qkvb);
+        add(l.attn, b.attn, T * l.ldat * sizeof(op_t), T * l.ldat * sizeof(op_t));
+        add(l.lse, b.lse, H * T * 4, H * T * 4);
+        add(l.u, b.u, T * F * sizeof(op_t), T * F * sizeof(op_t));
+        add(l.h_mid, b.h_mid, T * D * 4, T * D * 4);
+        const size_t st2 = (top && pooled_last && n < 1024) ? 4 : T * 4;       // pooled last layer: one LN2 statistic per view
+        add(l.mu2, b.mu2, st2, st2); add(l.rs2, b.rs2, st2, st2);
+        if (l.lora) add(l.x1ext, b.x1ext, T * c->ldx * sizeof(op_t), T * c->ldx * sizeof(op_t));
+        if (!first) {                                                          // LN1 backward: not reached in the first trained layer
+            add(l.h_in, b.h_in, T * D * 4, T * D * 4);
+            add(l.mu1, b.mu1, T * 4, T * 4); add(l.rs1, b.rs1, T * 4, T * 4);
+        }
+    }
+    add(c->cls_mean, c->sel_mean, 4, 4); add(c->cls_rstd, c->sel_rstd, 4, 4);
+    add(c->ycls, c->sel_y, D * 4, D * 4); add(c->feat, c->sel_f, E * 4, E * 4);
+    add(c->h_out[c->nS - 1], c->sel_h, T * D * 4, D * 4);                      // the CLS rows of the last layer's output
+    add(dlogits, c->sel_dz, K * 4, K * 4);
+    flush();
+    HIP_TRY(err);
+    return 0;
+}
+
+// sel_idx != null: dlogits is zero outside the n_sel views sel_idx lists (device, distinct view numbers < n; a top-k selection's
+// list: selected_views) — the backward then runs on those views' packed activations only.  Per row the same arithmetic as the full
+// backward; only the LoRA-gradient sums over rows leave out the zero rows.
+static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, bool inf_cleared = false, const long long* sel_idx = nullptr,
+                         int n_sel = 0) {
     if (!c || !dlogits) return fail(TTL_EINVAL, "null argument");
     if (!c->saved || c->saved_n != n) return fail(TTL_ESTATE, "no saved forward for %d sequences (run the forward with save_for_backward)", n);
     hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const bool packed = sel_idx != nullptr;
+    if (packed) {
+        if (c->text || n_sel < 1 || n_sel >= n || n_sel > c->sel_cap) return fail(TTL_EINVAL, "cannot restrict the backward to %d of %d views (capacity %d)", n_sel, n, c->sel_cap);
+        if ((rc = pack_selected_views(c, dlogits, n, sel_idx, n_sel, s))) return rc;
+        dlogits = c->sel_dz; n = n_sel;
+    }
+    struct PaddedRows { ttl_ctx* c; ~PaddedRows() { c->cur_padded = 0; } } padded_guard{c};
+    c->cur_padded = packed ? c->sel_rows : 0;
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H, r = c->r;
     const int causal = c->text;
     const int* pool = c->text ? c->pool : nullptr;
-    int rc;
     if (!inf_cleared) HIP_TRY(hipMemsetAsync(c->sc.i + SC_FOUND_INF, 0, sizeof(int), s));   // found_inf describes THIS backward's gradients
     float* dh = c->dh;      // gradient w.r.t. the residual stream at the current depth
     float* dh_alt = c->dh2;
     {
         Prof p(c, 5, s);
         HeadArgs a = head_args(c, c->h_out[c->nS - 1], nullptr, c->logits);
+        if (packed) { a.h = c->sel_h; a.T = 1; a.cls_mean = c->sel_mean; a.cls_rstd = c->sel_rstd; a.y = c->sel_y; a.f = c->sel_f; }
         HIP_TRY(launch_head_bwd(a, dlogits, c->dcls, c->dcls16, n, s));
     }
     const size_t per = (size_t)r * D;
@@ -984,7 +1074,13 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
     const int zoff[3] = {0, 0, 0};
     const float* dres_cls = nullptr;   // != null: d/d h_mid of the layer above is compact (CLS rows only)
     for (int i = c->L - 1; i >= c->c.layer_lo; --i) {
-        Layer& l = c->layers[i];
+        Layer lv = c->layers[i];        // (a copy: the packed run reads the saved activations from the SelBuf set)
+        if (packed) {
+            const ttl_ctx::SelBuf& b = c->selb[i - c->c.layer_lo];
+            lv.h_in = b.h_in; lv.h_mid = b.h_mid; lv.x1ext = b.x1ext; lv.qkv = b.qkv; lv.attn = b.attn; lv.u = b.u;
+            lv.lse = b.lse; lv.mu1 = b.mu1; lv.rs1 = b.rs1; lv.mu2 = b.mu2; lv.rs2 = b.rs2;
+        }
+        const Layer& l = lv;
         const bool first = (i == c->c.layer_lo);
         const bool lo_qkv = l.lora && c->nqkv > 0, lo_o = l.lora && c->has_o;
         const int need_dk = (!first || (l.lora && c->sk >= 0)) ? 1 : 0;   // the first trained layer needs dK only for a k_proj adapter
@@ -1140,6 +1236,14 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
 int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
     if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_backward_lora on a text-tower context (use ttl_text_backward_lora)");
     return backward_impl(c, dlogits, n, stream);
+}
+
+int ttl_vit_backward_lora_selected(ttl_ctx* c, const float* dlogits, int n, const int64_t* idx, int n_selected, void* stream) {
+    if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_backward_lora_selected on a text-tower context");
+    if (!c || !idx) return fail(TTL_EINVAL, "null argument");
+    // the same rule as the fused episode, so that both paths sum the LoRA gradients over the same rows
+    const bool pack = c->sel_cap && n_selected >= 1 && n_selected < n && n_selected <= c->sel_cap;
+    return backward_impl(c, dlogits, n, stream, false, pack ? (const long long*)idx : nullptr, pack ? n_selected : 0);
 }
 
 int ttl_text_backward_lora(ttl_ctx* c, const float* dlogits, void* stream) {
@@ -1332,7 +1436,10 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
                                         (a->objective == 1 && u > 0) ? 1 : 0, c->H_buf, c->idx_buf, c->n_buf, c->loss_buf, c->dlogits,
                                         c->loss_scratch, s, keep, c->sc.i + SC_FOUND_INF));
         }
-        if ((rc = backward_impl(c, c->dlogits, a->n_views, stream, true))) return rc;
+        {   // top-k selections: the gradient is zero outside the listed views -> backward on those views only
+            const int nsel = selected_views(c, a->n_views, a->mode, a->rho);
+            if ((rc = backward_impl(c, c->dlogits, a->n_views, stream, true, nsel ? c->idx_buf : nullptr, nsel))) return rc;
+        }
         {
             Prof p(c, 5, s);   // scaler.step(optimizer); scaler.update()  (deyo.py:186-188): whole step or nothing
             HIP_TRY(launch_adamw_fused(c->lora_p, c->lora_g, a->exp_avg, a->exp_avg_sq, c->lora_n, a->lr, a->beta1, a->beta2, a->eps,

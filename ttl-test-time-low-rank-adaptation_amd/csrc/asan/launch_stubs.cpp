@@ -174,6 +174,11 @@ hipError_t launch_gather_rows_op(const op_t* src, long long ld, const int* pool,
     mat_w(dst, n, cols, cols, 2);
     return hipSuccess;
 }
+hipError_t launch_gather_view_blocks(const GatherTable& t, const long long* idx, int n_sel, hipStream_t) {
+    span_r(idx, (size_t)n_sel * 8);     // (the index values come from a stubbed selection: only block 0 of every source is touched)
+    for (int i = 0; i < t.n; ++i) { span_r(t.e[i].src, t.e[i].block_bytes); span_w(t.e[i].dst, (size_t)n_sel * t.e[i].block_bytes); }
+    return hipSuccess;
+}
 hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* resid, int ldr, const float* bias, float* out,
                                 int ldc, hipStream_t, const int*) {
     span_r(part, (size_t)splits * M * N * 4); mat_r(resid, M, N, ldr, 4); span_r(bias, (size_t)N * 4); mat_w(out, M, N, ldc, 4);

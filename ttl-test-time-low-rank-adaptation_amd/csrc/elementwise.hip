@@ -331,6 +331,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const Tp* __restrict__
     dst[i] = src[((size_t)v * T + pool[v]) * ld + c];
 }
 
+// blockIdx = (chunk, selected view j, entry): dst block j of the entry = its src block idx[j]
+__global__ __launch_bounds__(256) void gather_view_blocks_kernel(const GatherTable t, const long long* __restrict__ idx) {
+    const GatherEntry e = t.e[blockIdx.z];
+    const int j = blockIdx.y;
+    const char* src = (const char*)e.src + (size_t)idx[j] * e.stride_bytes;
+    char* dst = (char*)e.dst + (size_t)j * e.block_bytes;
+    const size_t nth = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (((e.block_bytes | e.stride_bytes | (size_t)e.src | (size_t)e.dst) & 15) == 0) {
+        for (size_t i = i0; i < e.block_bytes / 16; i += nth) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
+    } else {
+        for (size_t i = i0; i < e.block_bytes / 4; i += nth) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+    }
+}
+
 // dst[c][r] = src[r][c]  (small fp32 matrices: logits between [views,prompts] and [prompts,views])
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -482,6 +496,19 @@ hipError_t launch_gather_rows_f32(const float* src, long long ld, const int* poo
 hipError_t launch_gather_rows_op(const op_t* src, long long ld, const int* pool, int T, op_t* dst, int n, int cols, hipStream_t s) {
     size_t tot = (size_t)n * cols;
     hipLaunchKernelGGL((gather_rows_kernel<op_t>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld, pool, T, dst, n, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_view_blocks(const GatherTable& t, const long long* idx, int n_sel, hipStream_t s) {
+    if (t.n < 1 || t.n > GATHER_MAX || n_sel < 1) return hipErrorInvalidValue;
+    unsigned long long big = 0;
+    for (int i = 0; i < t.n; ++i) {
+        if ((t.e[i].block_bytes | t.e[i].stride_bytes) & 3) return hipErrorInvalidValue;
+        big = t.e[i].block_bytes > big ? t.e[i].block_bytes : big;
+    }
+    unsigned gx = (unsigned)((big / 16 + 1023) / 1024);      // ~4 16-byte pieces per thread of the largest block
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(gather_view_blocks_kernel, dim3(gx, n_sel, t.n), dim3(256), 0, s, t, idx);
     return hipGetLastError();
 }
 

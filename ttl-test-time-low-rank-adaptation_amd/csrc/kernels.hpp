@@ -116,6 +116,14 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* me
 hipError_t launch_text_embed(const int* ids, const float* tok, const float* pos, float* h, int rows, int T, int D, hipStream_t s);
 // dst[v][0..cols) = src[(v*T + pool[v]) * ld + 0..cols): the pooled row of every sequence, compact
 hipError_t launch_gather_rows_f32(const float* src, long long ld, const int* pool, int T, float* dst, int n, int cols, hipStream_t s);
+// Per-view blocks of several buffers at once: for every entry e and j < n_sel, dst_e block j = src_e block idx[j] (+ first bytes).
+// The saved activations of the views a top-k selection kept (deyo.py:105, ttl.py:52), packed so that the backward runs on those views
+// only (api.hip backward_impl).  stride_bytes = distance between consecutive views in src, block_bytes = what is copied per view and the
+// distance between views in dst; all multiples of 4, the pointers 4-byte aligned (16-byte copies where everything is 16-byte aligned).
+struct GatherEntry { const void* src; void* dst; unsigned long long stride_bytes; unsigned long long block_bytes; };
+constexpr int GATHER_MAX = 64;
+struct GatherTable { GatherEntry e[GATHER_MAX]; int n; };
+hipError_t launch_gather_view_blocks(const GatherTable& t, const long long* idx, int n_sel, hipStream_t s);
 hipError_t launch_gather_rows_op(const op_t* src, long long ld, const int* pool, int T, op_t* dst, int n, int cols, hipStream_t s);
 // dst [C,R] = src [R,C]^T (fp32)
 hipError_t launch_transpose_f32(const float* src, int R, int C, float* dst, hipStream_t s);

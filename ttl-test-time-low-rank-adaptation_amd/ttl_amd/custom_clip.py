@@ -137,7 +137,7 @@ class _TextModeEngine:
         self.img.set_text_features(t, self.txt._scale)
         return self.img.head_logits(self.img.features(x))
 
-    def backward(self, dlogits):
+    def backward(self, dlogits, selection=None):      # (text mode: every prompt's features carry gradient, nothing to restrict)
         return self.txt.backward(dlogits)
 
     def bind_lora(self, flat):

@@ -103,7 +103,7 @@ def forward_and_adapt_sar(x, iter_, model, args, optimizer, scaler, deyo_margin,
     else:
         L = eng.entropy_select_loss(outputs, mode, rho=args.selection_p, thresh=math.log(1000), margin=margin,
                                     reweight=reweight)                           # deyo.py:102-108,159-181
-    eng.backward(L["dlogits"])                                                   # deyo.py:185-186
+    eng.backward(L["dlogits"], selection=L)                                      # deyo.py:185-186 (top-k: on the selected views only)
     for p, gslice in zip(params, _grad_views(eng, params)):
         p.grad = gslice
     # scaler.step(optimizer); scaler.update()  (deyo.py:187-188): the context's GradScaler state decides — the whole

@@ -154,10 +154,17 @@ class TTLEngine:
             self._check(self.lib.ttl_vit_forward(self._h, _ptr(x), x.shape[0], 0, None, _ptr(feats), _stream()))
         return feats
 
-    def backward(self, dlogits: torch.Tensor):
+    def backward(self, dlogits: torch.Tensor, selection=None):
+        """selection: the dict entropy_select_loss / tpt_select_loss returned for these dlogits.  When it names a top-k selection
+        (key "k": int(N * rho) views, listed in "idx"), the gradient is zero outside those views and the backward runs on them only
+        (include/ttl_hip.h ttl_vit_backward_lora_selected; the fused episode applies the same rule)."""
         d = dlogits.to(device=self.device, dtype=torch.float32).contiguous()
+        k = None if selection is None else selection.get("k")
         with torch.cuda.device(self.device):
-            self._check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
+            if k:
+                self._check(self.lib.ttl_vit_backward_lora_selected(self._h, _ptr(d), d.shape[0], _ptr(selection["idx"]), int(k), _stream()))
+            else:
+                self._check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
         return self.grads
 
     def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0, keep=None):
@@ -176,6 +183,7 @@ class TTLEngine:
             self._check(self.lib.ttl_ctx_entropy_select_loss(self._h, _ptr(z), N, K, int(mode), float(rho), float(th), float(margin),
                                                         float(reweight), _ptr(kp), _ptr(out["H"]), _ptr(out["idx"]), _ptr(out["n"]),
                                                         _ptr(out["loss"]), _ptr(out["dlogits"]), _stream()))
+        out["k"] = int(N * rho) if int(mode) == _lib.TTL_SEL_TOPK else None      # deyo.py:105: a fixed count, known without a sync
         return out
 
     def tpt_select_loss(self, logits, rho=0.1, idx=None, n=None):
@@ -191,6 +199,7 @@ class TTLEngine:
             self._check(self.lib.ttl_ctx_tpt_select_loss(self._h, _ptr(z), N, K, float(rho), 1 if reuse else 0, _ptr(out["H"]),
                                                     _ptr(out["idx"]), _ptr(out["n"]), _ptr(out["loss"]),
                                                     _ptr(out["dlogits"]), _stream()))
+        out["k"] = int(N * rho)                                                  # ttl.py:52
         return out
 
     # ---- PLPD filter of DeYO (deyo.py:115-151) on the device: destroyed views, keep mask; include/ttl_hip.h ttl_plpd_*

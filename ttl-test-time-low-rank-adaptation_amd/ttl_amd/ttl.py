@@ -50,7 +50,7 @@ def test_time_tuning(model, inputs, optimizer, scaler, args):
         out = eng.forward(inputs, save=True)
         sel = eng.tpt_select_loss(out, rho=args.selection_p, idx=None if sel is None else sel["idx"],
                                   n=None if sel is None else sel["n"])
-        eng.backward(sel["dlogits"])
+        eng.backward(sel["dlogits"], selection=sel)
         for p, g in zip(params, _grad_views(eng, params)):
             p.grad = g
         eng.optimizer_step(model._flat, eng.grads, model._opt_m, model._opt_v, step + 1, lr, betas, eps, wd)   # ttl.py:106-108
