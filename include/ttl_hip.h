@@ -303,7 +303,8 @@ int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int
                     const float* bias, const float* resid, int ldr, int rows_allocated, void* stream);
 /* The two fused forms the episode's wide projections use (csrc/gemm_huge.hip, csrc/gemm_big.hip), operand-dtype outputs:
  *   hm_T > 0 (q/k/v, modeling_clip.py:309-311): C is written head-major — row m = view * hm_T + t, column plane * D + head * 64 + d
- *            (D = N / 3) goes to C[((view * 3 + plane) * D + head * 64) * hm_T + t * 64 + d]; C2 must be NULL;
+ *            (D = N / 3) goes to C[((view * 3 + plane) * D + head * 64) * hm_T + t * 64 + d] (C holds ceil(M / hm_T) whole views);
+ *            C2 must be NULL;
  *   hm_T == 0 (fc1, modeling_clip.py:346-348): C = quick_gelu(product + bias) and, if C2 != NULL, C2 = product + bias.
  * rows_allocated as ttl_gemm_nt_epi.  TTL_EINVAL when the shape does not run on a big-M kernel (M < 1024, N % 256, ...). */
 int ttl_gemm_nt_fused(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2, int M, int N, int K,

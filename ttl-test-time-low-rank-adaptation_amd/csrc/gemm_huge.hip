@@ -87,8 +87,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((size_t)(a.N - 1) * a.ldb + a.K) * sizeof(op_t)), RSRC);
     const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, RSRC);
     // outputs: rows >= M lie past num_records (row-major) or get an out-of-range offset (head-major) and are dropped
+    // (head-major: whole [T][64] tiles of ceil(M / T) views — a trailing partial view's rows lie inside its own view block)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-        a.C, 0, (int)(EPI == EPI_OP_HM ? (size_t)M * a.N * sizeof(op_t) : (size_t)M * a.ldc * sizeof(op_t)), RSRC);
+        a.C, 0, (int)(EPI == EPI_OP_HM ? (size_t)((M + a.hm_T - 1) / a.hm_T) * a.hm_T * a.N * sizeof(op_t) : (size_t)M * a.ldc * sizeof(op_t)), RSRC);
     const __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.C2, 0, (int)(EPI == EPI_GELU_C2 ? (size_t)M * a.ldc2 * sizeof(op_t) : 0), RSRC);
     const int voA = (int)((r8 * a.lda + cs * 8) * sizeof(op_t));
     const int voB = (int)((4 * (8 * wave + r8) * a.ldb + cs * 8) * sizeof(op_t));   // image row 32 nt + c of a wave's 128 columns holds column 4 c + nt
@@ -273,7 +274,7 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // 32-bit buffer offsets: every operand / output extent stays below 2 GiB
     const size_t lim = (size_t)1 << 31;
     if ((size_t)a.M * a.lda * sizeof(op_t) >= lim || (size_t)a.N * a.ldb * sizeof(op_t) >= lim) return false;
-    if (a.hm_T) { if ((size_t)a.M * a.N * sizeof(op_t) >= lim) return false; }
+    if (a.hm_T) { if (((size_t)a.M + a.hm_T) * a.N * sizeof(op_t) >= lim) return false; }
     else if ((size_t)a.M * a.ldc * sizeof(op_t) >= lim || (a.C2 && (size_t)a.M * a.ldc2 * sizeof(op_t) >= lim)) return false;
     return true;
 }
