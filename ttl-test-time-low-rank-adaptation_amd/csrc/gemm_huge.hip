@@ -66,14 +66,31 @@ __device__ __forceinline__ void mix() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// slot -> tile.  order 0: the XCDs own contiguous ranges of the row-major tile list (xcd_remap); order 1 / 2: XCD x (= slot & 7) owns
+// the row panels [x * ntm / 8, (x + 1) * ntm / 8) and walks them column-major (all its panels of one 256-column weight slice before the
+// next slice) / row-major; slots past an XCD's last tile are empty (the launch has 8 * max_x(tiles of x) slots).
+__device__ __forceinline__ bool huge_tile_of(int order, int slot, int ntm, int ntn, int& rt, int& ct) {
+    if (order == 0) {
+        const int t = xcd_remap(slot, ntm * ntn);
+        rt = t / ntn; ct = t - rt * ntn;
+        return true;
+    }
+    const int x = slot & 7, j = slot >> 3;
+    const int r0 = x * ntm / 8, nr = (x + 1) * ntm / 8 - r0;
+    if (j >= nr * ntn) return false;
+    if (order == 1) { ct = j / nr; rt = r0 + (j - ct * nr); }
+    else { const int jr = j / ntn; rt = r0 + jr; ct = j - jr * ntn; }
+    return true;
+}
+
 template <int EPI>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_huge_kernel(const GemmArgs a, int ntm, int ntn) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_huge_kernel(const GemmArgs a, int ntm, int ntn, int order, int nslots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l32 = lane & 31, lh = lane >> 5;
-    const int M = a.M, nk = a.K / BK, ntiles = ntm * ntn;
+    const int M = a.M, nk = a.K / BK, ntiles = nslots;
     // ---- fragment addresses: MFMA 32x32x16 operand = row l32 of the wave's slab, 16-B chunk 2 s + lh of K sub-step s
     const int sw = (l32 >> 1) & 7;
     const int fA0 = (wm * 128 + l32) * 128 + ((lh ^ sw) << 4);
@@ -130,9 +147,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     };
 
     int slot = blockIdx.x;
-    if (slot >= ntiles) return;
     int row0, col0;
-    { const int t = xcd_remap(slot, ntiles); const int rt = t / ntn; row0 = rt * BM; col0 = (t - rt * ntn) * BN; }
+    {
+        int rt, ct;
+        while (slot < ntiles && !huge_tile_of(order, slot, ntm, ntn, rt, ct)) slot += gridDim.x;
+        if (slot >= ntiles) return;
+        row0 = rt * BM; col0 = ct * BN;
+    }
     dma_bias(col0); dma_b(B0, col0, 0); dma_a(A0, row0, 0); dma_a(A0 + SLOT, row0, 1);
     bool first = true;
     for (;;) {
@@ -188,12 +209,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         body(kt, std::true_type{}, std::false_type{}, std::true_type{}); ++kt;
         body(kt, std::false_type{}, std::false_type{}, std::true_type{});
         // ---- every slot is free: the next tile's bias and first K-tiles go out before the last MFMAs and the stores of this one
-        const int nslot = slot + gridDim.x;
+        int nslot = slot + gridDim.x;
         int nrow0 = 0, ncol0 = 0;
-        if (nslot < ntiles) {
-            const int t = xcd_remap(nslot, ntiles); const int rt = t / ntn; nrow0 = rt * BM; ncol0 = (t - rt * ntn) * BN;
-            dma_bias(ncol0); dma_b(B0, ncol0, 0); dma_a(A0, nrow0, 0);
+        {
+            int rt = 0, ct = 0;
+            while (nslot < ntiles && !huge_tile_of(order, nslot, ntm, ntn, rt, ct)) nslot += gridDim.x;
+            nrow0 = rt * BM; ncol0 = ct * BN;
         }
+        if (nslot < ntiles) { dma_bias(ncol0); dma_b(B0, ncol0, 0); dma_a(A0, nrow0, 0); }
         mma(1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue: register r of sub-tile (mt, j) is row 32 mt + 8 (r >> 2) + 4 lh + (r & 3), column 4 l32 + j of the wave's slab
@@ -245,8 +268,13 @@ hipError_t launch_huge_t(const GemmArgs& a, int max_blocks, hipStream_t s) {
     hipError_t e = ensure_smem((const void*)gemm_huge_kernel<EPI>, 5 * SLOT, done);
     if (e != hipSuccess) return e;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    const int grid = ntm * ntn < max_blocks ? ntm * ntn : max_blocks;
-    hipLaunchKernelGGL((gemm_huge_kernel<EPI>), dim3(grid), dim3(NT), 5 * SLOT, s, a, ntm, ntn);
+    // tile order: measured neutral (profiles/r05_experiments.txt r05p: what the other orders save is re-fetched from the Infinity Cache)
+    static const int order_env = [] { const char* v = getenv("TTL_GEMM_HUGE_ORDER"); return v ? atoi(v) : 0; }();
+    const int order = (ntm >= 8) ? order_env : 0;
+    const int nslots = order ? 8 * ((ntm + 7) / 8) * ntn : ntm * ntn;
+    int grid = nslots < max_blocks ? nslots : max_blocks;
+    if (order) grid = (grid / 8) * 8 ? (grid / 8) * 8 : 8;      // whole XCD rounds: slot & 7 must stay the block's XCD label
+    hipLaunchKernelGGL((gemm_huge_kernel<EPI>), dim3(grid), dim3(NT), 5 * SLOT, s, a, ntm, ntn, order, nslots);
     return hipGetLastError();
 }
 
