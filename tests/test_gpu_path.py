@@ -887,13 +887,16 @@ def test_clip_like_activation_outliers(name, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16", "strict"])
-@pytest.mark.parametrize("name,objective", [("b16_n64_k200_ent1", "deyo"), ("b16_n64_k200_tpt", "tpt"), ("l14_n64_k200", "deyo")])
-def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objective):
+@pytest.mark.parametrize("name,objective,n_updates", [("b16_n64_k200_ent1", "deyo", 1), ("b16_n64_k200_tpt", "tpt", 1), ("l14_n64_k200", "deyo", 1),
+                                                      ("b16_n64_k200_qkvo", "deyo", 1), ("b16_r32_n128_k1000_steps2", "deyo", 2),
+                                                      ("b16_n64_k200_tpt", "tpt", 3)])
+def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objective, n_updates):
     """A top-k selection (deyo.py:105 --filter_ent 1, ttl.py:52 TPT) leaves the loss gradient zero outside int(N * rho) = 6 of 64 views:
     the backward packs those views' saved activations and runs on them alone (api.hip backward_impl, TTL_BWD_COMPACT).  Against the
     full backward of the same context type (TTL_BWD_COMPACT=0): per row the same arithmetic, so every LoRA gradient agrees to the
     fp32 re-association of its sum over rows; selection lists, logits and the skipped-view rows are identical.  The step-wise entry
-    (ttl_vit_backward_lora_selected) and the fused episode apply the same rule: bitwise equal adapters."""
+    (ttl_vit_backward_lora_selected) and the fused episode apply the same rule: bitwise equal adapters.  Also with adapters on all
+    four projections, with rank 32 on 128 views over two updates (12 views per update), and with TPT's cached selection over three."""
     g, cfg, W, x, lora0, tf = load_case(name)
     n = x.shape[0]
     rho = 0.1
@@ -903,22 +906,22 @@ def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objec
         monkeypatch.setenv("TTL_BWD_COMPACT", on)            # read when a context is created
         eng, flat, names = make_engine(cfg, W, lora0, tf, n, precision=precision)
         snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
-        l1 = eng.episode(xd, snap, m, v, objective=objective, mode=1, rho=rho).clone()
+        l1 = eng.episode(xd, snap, m, v, objective=objective, mode=1, rho=rho, n_updates=n_updates).clone()
         torch.cuda.synchronize()
         idx, nsel = eng.last_selection(n)
         res[on] = dict(l1=l1.cpu().numpy(), grads=eng.grads.clone().cpu().numpy(), flat=flat.clone().cpu().numpy(), idx=np.asarray(idx))
-        if on == "1":       # the same update through the step-wise entry points lands on the same bits
+        if on == "1" and n_updates == 1:       # the same update through the step-wise entry points lands on the same bits
             eng.lora_reset(flat, snap, m, v)
             z = eng.forward(xd, save=True)
             L = eng.tpt_select_loss(z, rho=rho) if objective == "tpt" else eng.entropy_select_loss(z, 1, rho=rho)
-            assert L["k"] == int(n * rho) == 6
+            assert L["k"] == int(n * rho)
             eng.backward(L["dlogits"], selection=L)
             eng.optimizer_step(flat, eng.grads, m, v, 1, n_selected=L["n"])
             torch.cuda.synchronize()
             assert np.array_equal(eng.grads.cpu().numpy(), res[on]["grads"])
             assert np.array_equal(flat.cpu().numpy(), res[on]["flat"])
         eng.close()
-    assert np.array_equal(res["1"]["idx"], res["0"]["idx"]) and len(res["1"]["idx"]) == 6
+    assert np.array_equal(res["1"]["idx"], res["0"]["idx"]) and len(res["1"]["idx"]) == int(n * rho)
     ga, gb = res["1"]["grads"], res["0"]["grads"]
     assert np.isfinite(ga).all() and np.abs(gb).max() > 0
     # per parameter tensor: sums of the same fp32 products in another grouping
@@ -928,8 +931,15 @@ def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objec
         if np.abs(b).max() == 0:
             assert not a.any(), k
         else:
-            bound(f"packed_backward/{name}/{objective}/{precision}/grad", max_rel(a, b), 2e-5)
+            # (one update: re-association only.  Later updates start from adapters in which the sign-like first AdamW step has flipped
+            #  the elements whose gradient sits inside that noise — a few of 10^5 entries of B by 2 * lr each — and dA of the next
+            #  update is linear in B: 2e-6 on the strict build after two updates, 2e-3 / 2e-2 on bf16 / fp16 after three TPT updates.
+            #  The same mechanism as between any two correct implementations)
+            bound(f"packed_backward/{name}/{objective}/{n_updates}/{precision}/grad", max_rel(a, b), 2e-5 if n_updates == 1 else 0.1)
     # the first AdamW step is sign-like: adapters agree wherever the gradient is not within that noise of zero
     d = np.abs(res["1"]["flat"] - res["0"]["flat"])
-    assert (d > 1e-6).mean() < 2e-3
+    if n_updates == 1:
+        assert (d > 1e-6).mean() < 2e-3
+    else:       # every later step starts from the flipped elements of the one before: count those a tenth of a step (lr = 5e-3) apart
+        bound(f"packed_backward/{name}/{objective}/{n_updates}/{precision}/frac_beyond_0.1lr", (d > 5e-4).mean(), 0.1)
     assert max_rel(res["1"]["l1"], res["0"]["l1"]) < (1e-4 if precision == "strict" else 5e-3)
