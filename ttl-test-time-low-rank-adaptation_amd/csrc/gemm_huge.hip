@@ -1,14 +1,16 @@
-// Wide, short-K big-M GEMM on 256 x 256 x 64 tiles and FOUR waves:  C[M,N] = A[M,K] · B[N,K]^T (+ fused epilogue) for the launches
-// with N >= 2304 and K <= 1024 — q/k/v (HF modeling_clip.py:309-311, head-major output) and fc1 (modeling_clip.py:346-348, quick_gelu).
+// Wide, short-K big-M GEMM on 256 x 256 x 64 tiles and FOUR waves:  C[M,N] = A[M,K] · B[N,K]^T (+ fused epilogue) for launches with
+// N >= 2304 and K <= 1024.  It runs the q/k/v projection (HF modeling_clip.py:309-311, head-major output); it also carries fc1's
+// epilogues (modeling_clip.py:346-348, quick_gelu + the pre-activation), which stay on gemm_big.hip by default (gemm_huge_applicable).
 //
 // Why a second big-M kernel: these launches have 12-16 K-steps per tile, so what a tile costs is set by the bytes staged per FLOP and
 // by the per-tile prologue / epilogue as much as by the K loop.  gemm_big.hip's 160 x 256 tile stages 1 byte per 98 FLOP on eight
 // waves (80 x 64 outputs per wave: 147 KiB of LDS fragment reads per K-step); here a wave owns 128 x 128 outputs (4 x 4 MFMA
 // 32x32x16 tiles, 256 accumulator registers): 1 staged byte per 128 FLOP and 131 KiB of fragment reads per K-step for 1.6x the FLOP.
-// Measured on the 64-view ViT-B/16 shapes (fp16, M = 12 608, cold operands, tools/gemm_huge_bench.py): q/k/v 49.4 us against
-// 52.9 us (vendor library 48.2), fc1 70.0 against 67.7 (three rounds of 256 for 600 tiles; library 64.9) — and, what counts with three
-// episodes in flight (a launch costs tiles x time per tile there), 11.1 against 12.5 and 14.0 against 16.0 ms of
-// CU-time per launch.
+// Measured on the 64-view ViT-B/16 shapes (fp16, M = 12 608, cold operands; row-major outputs: profiles/r05_experiments.txt r05n;
+// with the episode's epilogues: tools/gemm_huge_bench.py): q/k/v 49.4 us against 52.9 us (vendor library 48.2), head-major 53.9
+// against 55.7; fc1 70.0 against 67.7, with both outputs 79.1 against 70.7 (600 tiles = three rounds of 256, and 128 store
+// instructions per lane behind which the next tile's first wait has to drain most of them: vmcnt counts to 63).  In situ, three
+// episodes in flight: q/k/v +1.1 % images/s, fc1 +0.2 % (profiles/r05_huge_sweep_fp16.txt).
 //
 //   * operands by LDS-DMA only (buffer_load_dwordx4 ... lds: one per-lane offset per operand, everything else wave-uniform; rows past
 //     M read as zeros through the buffer range check), no staging registers:
