@@ -305,7 +305,9 @@ int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int
  *   hm_T > 0 (q/k/v, modeling_clip.py:309-311): C is written head-major — row m = view * hm_T + t, column plane * D + head * 64 + d
  *            (D = N / 3) goes to C[((view * 3 + plane) * D + head * 64) * hm_T + t * 64 + d] (C holds ceil(M / hm_T) whole views);
  *            C2 must be NULL;
- *   hm_T == 0 (fc1, modeling_clip.py:346-348): C = quick_gelu(product + bias) and, if C2 != NULL, C2 = product + bias.
+ *   hm_T == 0 (fc1, modeling_clip.py:346-348): C = quick_gelu(product + bias) and, if C2 != NULL, C2 = product + bias;
+ *   hm_T == -1 (its backward: d/d u of g = quick_gelu(u) folded into the fc2 dgrad): C = product * quick_gelu'(C2), C2 = the saved
+ *            pre-activation u (read only, ldc2), bias must be NULL.
  * rows_allocated as ttl_gemm_nt_epi.  TTL_EINVAL when the shape does not run on a big-M kernel (M < 1024, N % 256, ...). */
 int ttl_gemm_nt_fused(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2, int M, int N, int K,
                       const float* bias, int hm_T, int rows_allocated, void* stream);

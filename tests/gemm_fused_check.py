@@ -10,10 +10,11 @@ import torch
 
 TDT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 OUT_TOL = {"bf16": 6e-3, "fp16": 8e-4}      # one rounding of the output to the operand type
-# (M, N, K, T): T > 0 = head-major q/k/v of views of T tokens, 0 = fc1.  ViT-B/16 and L/14 episode shapes, a row count that ends
+# (M, N, K, T): T > 0 = head-major q/k/v of views of T tokens, 0 = fc1, -1 = the MLP dgrad (product * quick_gelu'(u)).  ViT-B/16 and L/14 episode shapes, a row count that ends
 # inside a tile, the shortest K the 256 x 256 kernel takes (3 K-tiles) and its longest (16), one tile per block and several
 SHAPES = [(12608, 2304, 768, 197), (12608, 3072, 768, 0), (16448, 3072, 1024, 257), (16448, 4096, 1024, 0), (5122, 2304, 192, 197),
-          (5000, 3072, 192, 0), (1576, 2304, 832, 197), (12708, 2304, 768, 197)]       # (the last one ends inside a view)
+          (5000, 3072, 192, 0), (1576, 2304, 832, 197), (12708, 2304, 768, 197),       # (this one ends inside a view)
+          (12608, 3072, 768, -1), (16448, 4096, 1024, -1), (5000, 3072, 192, -1)]
 
 
 def max_rel(a, b):
@@ -29,7 +30,10 @@ def takes_huge(M, N, T):
     """csrc/gemm_huge.hip gemm_huge_applicable, for the shapes of this file: the launch family is switched on and the launch has
     256 x 256 tiles for TTL_GEMM_HUGE_MIN_FILL (default 85) percent of the CUs."""
     mode = huge_mode()
-    if not (mode == 1 or (mode == 2 and T > 0) or (mode == 3 and T == 0)):
+    if T == -1:
+        if mode == 0 or os.environ.get("TTL_GEMM_HUGE_DGRAD", "0") == "0":
+            return False
+    elif not (mode == 1 or (mode == 2 and T > 0) or (mode == 3 and T == 0)):
         return False
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = (M + 255) // 256 * (N // 256)
@@ -49,13 +53,22 @@ def check(lib, prec, M, N, K, T, lda_pad=0, with_bias=True):
     bias = torch.randn(N, generator=g).cuda() if with_bias else None
     Mp = (M + 1279) // 1280 * 1280 + 320
     c = torch.full((Mp, N), 7.0, device="cuda", dtype=TDT[prec])
-    c2 = None if T else torch.full((Mp, N), 7.0, device="cuda", dtype=TDT[prec])
+    c2 = None if T > 0 else torch.full((Mp, N), 7.0, device="cuda", dtype=TDT[prec])
+    if T == -1:       # the saved pre-activation of the MLP dgrad form
+        with_bias, bias = False, None
+        c2[:M] = (torch.randn(M, N, generator=g) * 1.5).to(TDT[prec]).cuda()
+        u_in = c2.clone()
     rc = lib.ttl_gemm_nt_fused(P(abuf), K + lda_pad, P(b), K, P(c), N, P(c2), N, M, N, K, P(bias), T, Mp, stream)
     assert rc == 0, (rc, lib.ttl_last_error())
     torch.cuda.synchronize()
     want = a.float() @ b.float().t() + (bias if with_bias else 0.0)
     tol = OUT_TOL[prec]
-    if T:
+    if T == -1:
+        u = u_in[:M].float()
+        sg = torch.sigmoid(1.702 * u)
+        assert max_rel(c[:M].float().cpu().numpy(), (want * (sg * (1.0 + 1.702 * u * (1.0 - sg)))).cpu().numpy()) < tol
+        assert torch.equal(c2, u_in)           # u is read only
+    elif T:
         views, D = M // T, N // 3
         got = c.reshape(-1)[: views * T * N].float().reshape(views, 3, D // 64, T, 64)
         ref = want[: views * T].reshape(views, T, 3, D // 64, 64).permute(0, 2, 3, 1, 4)
@@ -68,11 +81,11 @@ def check(lib, prec, M, N, K, T, lda_pad=0, with_bias=True):
         assert max_rel(c2[:M].float().cpu().numpy(), want.cpu().numpy()) < tol
         assert max_rel(c[:M].float().cpu().numpy(), (want * torch.sigmoid(1.702 * want)).cpu().numpy()) < tol
     # nothing behind the rows a launch may store: row M on the 256 x 256 kernel (range-checked stores), round_up(M, 160) otherwise
-    top = M if huge_on else (M + 159) // 160 * 160
-    if T:
+    top = M if huge_on else ((M + 127) // 128 * 128 if T == -1 else (M + 159) // 160 * 160)
+    if T > 0:
         top = (top + T - 1) // T * T        # head-major: whole views
     assert (c[top:].float() == 7.0).all()
-    if c2 is not None:
+    if c2 is not None and T == 0:
         assert (c2[top:].float() == 7.0).all()
 
 

@@ -330,7 +330,8 @@ def test_gemm_wide_fused_forms(lib, prec):
     the pre-activation the backward reads) through ttl_gemm_nt_fused — the forms no other kernel-level entry reaches — on both
     kernels that have them: in this process the default split (q/k/v launches with tiles for most of the CUs on gemm_huge.hip's 256 x 256
     four-wave tiles, everything else on gemm_big.hip's 160 x 256), in child processes TTL_GEMM_HUGE=0 (everything on gemm_big.hip)
-    and =1 with the round-fill rule off (everything on gemm_huge.hip).
+    and =1 with the round-fill rule off and the MLP-dgrad form switched on (everything on gemm_huge.hip); the MLP-dgrad form
+    (product * quick_gelu'(u)) runs on gemm_big.hip's 128-row tiles by default.
     The strict build has neither form (row-major q/k/v, its own GEMM): the entry must say so."""
     import os, subprocess, sys
     import gemm_fused_check as G
@@ -344,7 +345,7 @@ def test_gemm_wide_fused_forms(lib, prec):
     G.check(lib, prec, 12608, 2304, 768, 197, lda_pad=64)            # A as the first K columns of a wider buffer
     G.check(lib, prec, 12608, 2304, 768, 197, with_bias=False)       # null bias
     for mode in ("0", "1"):      # (mode 1 with the round-fill rule off: every shape on gemm_huge.hip)
-        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0"),
+        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0", TTL_GEMM_HUGE_DGRAD="1"),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and f"ok {prec} mode {mode}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
         assert f"on gemm_huge: {len(G.SHAPES) if mode == '1' else 0}" in out.stdout, out.stdout[-500:]

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd"))
 SHAPES = [("q/k/v  B/16", 12608, 2304, 768, 197), ("fc1    B/16", 12608, 3072, 768, 0), ("q/k/v  L/14", 16448, 3072, 1024, 257),
-          ("fc1    L/14", 16448, 4096, 1024, 0)]
+          ("fc1    L/14", 16448, 4096, 1024, 0), ("MLPdgr B/16", 12608, 3072, 768, -1), ("MLPdgr L/14", 16448, 4096, 1024, -1)]
 
 
 def child(prec):
@@ -39,23 +39,23 @@ def child(prec):
     for name, M, N, K, T in SHAPES:
         Mp = (M + 1279) // 1280 * 1280 + 320
         sets = [(torch.randn(M, K, device="cuda").to(dt), (torch.randn(N, K, device="cuda") * 0.05).to(dt),
-                 torch.empty(Mp, N, device="cuda", dtype=dt), None if T else torch.empty(Mp, N, device="cuda", dtype=dt)) for _ in range(6)]
+                 torch.empty(Mp, N, device="cuda", dtype=dt), None if T > 0 else torch.randn(Mp, N, device="cuda").to(dt)) for _ in range(6)]
         bias = torch.randn(N, device="cuda")
         bh = bias.to(dt)
 
         def ours(i):
             a, b, c, c2 = sets[i % 6]
-            assert lib.ttl_gemm_nt_fused(P(a), K, P(b), K, P(c), N, P(c2), N, M, N, K, P(bias), T, Mp, s) == 0
+            assert lib.ttl_gemm_nt_fused(P(a), K, P(b), K, P(c), N, P(c2), N, M, N, K, None if T == -1 else P(bias), T, Mp, s) == 0
 
         def vendor(i):
             a, b, _, _ = sets[i % 6]
-            y = torch.nn.functional.linear(a, b, bh)
-            if not T:
-                torch.nn.functional.gelu(y)        # (the library has no fused two-output form: its second pass is part of what it costs)
+            y = torch.nn.functional.linear(a, b, None if T == -1 else bh)
+            if T <= 0:
+                torch.nn.functional.gelu(y)        # (the library has no fused two-output / gelu' form: its second pass is part of what it costs)
         t_o = [timeit(ours) for _ in range(5)]
         t_v = [timeit(vendor) for _ in range(5)]
         print(f"{name}  M={M} N={N} K={K}  ttl_gemm_nt_fused {statistics.median(t_o):6.1f} us ({min(t_o):.1f}-{max(t_o):.1f})   "
-              f"torch linear{'' if T else ' + gelu'} {statistics.median(t_v):6.1f} us", flush=True)
+              f"torch linear{'' if T > 0 else ' + gelu'} {statistics.median(t_v):6.1f} us", flush=True)
 
 
 if __name__ == "__main__":
@@ -65,6 +65,6 @@ if __name__ == "__main__":
     prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
     for mode, label in (("1", "gemm_huge.hip (256 x 256, four waves)"), ("0", "gemm_big.hip (160 x 256, eight waves)"), ("1", "gemm_huge.hip again")):
         print(f"---- TTL_GEMM_HUGE={mode}: {label}   [{prec}]", flush=True)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), prec, "--child"], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0"))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), prec, "--child"], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0", TTL_GEMM_HUGE_DGRAD="1"))
         if r.returncode:
             sys.exit(r.returncode)

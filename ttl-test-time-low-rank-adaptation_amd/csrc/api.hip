@@ -1597,14 +1597,16 @@ int ttl_gemm_nt_epi(const void* A, int lda, const void* B, int ldb, void* C, int
 int ttl_gemm_nt_fused(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2, int M, int N, int K,
                       const float* bias, int hm_T, int rows_allocated, void* stream) {
     if (!A || !B || !C) return fail(TTL_EINVAL, "null argument");
-    if (hm_T < 0 || (hm_T && (C2 || N % 192))) return fail(TTL_EINVAL, "head-major output: N = 3 * heads * 64, no second output");
+    if (hm_T < -1 || (hm_T > 0 && (C2 || N % 192))) return fail(TTL_EINVAL, "head-major output: N = 3 * heads * 64, no second output");
+    if (hm_T == -1 && (!C2 || bias)) return fail(TTL_EINVAL, "MLP dgrad form: C2 = the saved pre-activation, no bias");
     GemmArgs a = {};
     a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
-    a.C2 = (op_t*)C2; a.ldc2 = ldc2; a.bias = bias;
+    a.bias = bias;
+    if (hm_T == -1) { a.aux = (const op_t*)C2; a.ldaux = ldc2; } else { a.C2 = (op_t*)C2; a.ldc2 = ldc2; }
     a.padded = rows_allocated >= round_up(M, 1280) ? rows_allocated : 0;
-    if (hm_T) { a.hm_T = hm_T; a.hm_magic = qkv_hm_magic(hm_T, M + 320); }
-    const GemmEpi epi = hm_T ? EPI_OP : EPI_GELU;
-    if ((hm_T && !a.hm_magic) || !gemm_takes_big(epi, a)) return fail(TTL_EINVAL, "not a big-M launch (M >= 1024, N %% 256 == 0, K %% 64 == 0, padded rows)");
+    if (hm_T > 0) { a.hm_T = hm_T; a.hm_magic = qkv_hm_magic(hm_T, M + 320); }
+    const GemmEpi epi = hm_T > 0 ? EPI_OP : hm_T == 0 ? EPI_GELU : EPI_GELU_BWD;
+    if ((hm_T > 0 && !a.hm_magic) || !gemm_takes_big(epi, a)) return fail(TTL_EINVAL, "not a big-M launch (M >= 1024, N %% 256 == 0, K %% 64 == 0, padded rows)");
     hipError_t e = launch_gemm(epi, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "gemm: %s", hipGetErrorString(e));
     return 0;

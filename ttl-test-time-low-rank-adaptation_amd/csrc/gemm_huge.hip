@@ -47,6 +47,7 @@ constexpr int BM = 256, BN = 256, BK = 64, NT = 256;
 constexpr int SLOT = 32768;
 constexpr int EPI_GELU_C2 = 100;   // internal: EPI_GELU with the second (pre-activation) output
 constexpr int EPI_OP_HM = 101;     // internal: EPI_OP into a head-major q/k/v buffer (GemmArgs::hm_T, kernels.hpp QkvLayout)
+constexpr int EPI_DGELU = 105;     // EPI_GELU_BWD (MLP dgrad: C = product * quick_gelu'(u)); u of the tile is read behind the last barrier
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {     // s_waitcnt vmcnt(N) lgkmcnt(0)  (gfx9 encoding, as gemm_big.hip)
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
         a.C, 0, (int)(EPI == EPI_OP_HM ? (size_t)((M + a.hm_T - 1) / a.hm_T) * a.hm_T * a.N * sizeof(op_t) : (size_t)M * a.ldc * sizeof(op_t)), RSRC);
     const __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.C2, 0, (int)(EPI == EPI_GELU_C2 ? (size_t)M * a.ldc2 * sizeof(op_t) : 0), RSRC);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, (int)(EPI == EPI_DGELU ? (size_t)M * a.ldaux * sizeof(op_t) : 0), RSRC);
     const int voA = (int)((r8 * a.lda + cs * 8) * sizeof(op_t));
     const int voB = (int)((4 * (8 * wave + r8) * a.ldb + cs * 8) * sizeof(op_t));   // image row 32 nt + c of a wave's 128 columns holds column 4 c + nt
     char* const A0 = smem;
@@ -221,6 +223,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (nslot < ntiles) { dma_bias(ncol0); dma_b(B0, ncol0, 0); dma_a(A0, nrow0, 0); }
         mma(1);
         __builtin_amdgcn_sched_barrier(0);
+        // MLP dgrad: the lane's 64 x 4 pre-activations of this tile (rows >= M: zeros).  Requested behind the last MFMAs (the fragment
+        // registers are free then: 128 more live registers do not fit beside them); the wait for them covers the next tile's first pieces
+        [[maybe_unused]] u32x2 ur[4][16];
+        if constexpr (EPI == EPI_DGELU) {
+            const int vou = (int)(((wm * 128 + 4 * lh) * a.ldaux + wn * 128 + 4 * l32) * sizeof(op_t));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ur[mt][r] = __builtin_amdgcn_raw_buffer_load_b64(rsU, vou, (int)(((size_t)(row0 + mt * 32 + 8 * (r >> 2) + (r & 3)) * a.ldaux + col0) * sizeof(op_t)), 0);
+        }
         // ---- epilogue: register r of sub-tile (mt, j) is row 32 mt + 8 (r >> 2) + 4 lh + (r & 3), column 4 l32 + j of the wave's slab
         const int n0 = col0 + wn * 128 + 4 * l32;
         int vo, vo2 = 0;
@@ -253,9 +266,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_C2) {
                         v0 = quick_gelu_f(v0); v1 = quick_gelu_f(v1); v2 = quick_gelu_f(v2); v3 = quick_gelu_f(v3);
                     }
+                    if constexpr (EPI == EPI_DGELU) {
+                        const u32x2 t = ur[mt][r];
+                        v0 *= quick_gelu_grad_f(op_lo(t[0])); v1 *= quick_gelu_grad_f(op_hi(t[0]));
+                        v2 *= quick_gelu_grad_f(op_lo(t[1])); v3 *= quick_gelu_grad_f(op_hi(t[1]));
+                    }
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, rsC, vo,
                                                           (int)(((size_t)(row0 + mrow) * a.ldc + col0) * sizeof(op_t)),
-                                                          (EPI != EPI_OP && TTL_GEMM_NT_GELU) ? 2 : 0);
+                                                          ((EPI == EPI_GELU || EPI == EPI_GELU_C2) && TTL_GEMM_NT_GELU) ? 2 : 0);
                 }
             }
         if (nslot >= ntiles) break;
@@ -288,8 +306,13 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // 2.883 -> 2.850 ms; fc1 +0.2 % and 2.883 -> 2.99 ms (600 tiles = three rounds of 256, two 77-MB outputs per launch): fc1 stays
     // on gemm_big.hip, its epilogues here are kept for the tests and for other shapes.
     static const int mode = [] { const char* v = getenv("TTL_GEMM_HUGE"); return v ? atoi(v) : 2; }();
-    if (mode <= 0 || (epi != EPI_OP && epi != EPI_GELU)) return false;
-    if ((mode == 2 && epi != EPI_OP) || (mode == 3 && epi != EPI_GELU)) return false;
+    // TTL_GEMM_HUGE_DGRAD=1: the MLP dgrad (EPI_GELU_BWD, N = F) too — measured slower (95.9 vs 86.1 us one at a time, no change in situ:
+    // its u tile has to be read behind the last MFMAs, profiles/r05_experiments.txt r05q): off
+    static const int dgrad = [] { const char* v = getenv("TTL_GEMM_HUGE_DGRAD"); return v ? atoi(v) : 0; }();
+    if (mode <= 0) return false;
+    if (epi == EPI_GELU_BWD) { if (!dgrad || !a.aux || (size_t)a.M * a.ldaux * sizeof(op_t) >= ((size_t)1 << 31)) return false; }
+    else if (epi != EPI_OP && epi != EPI_GELU) return false;
+    else if ((mode == 2 && epi != EPI_OP) || (mode == 3 && epi != EPI_GELU)) return false;
     if (a.M < 1024 || a.N < 2304 || a.N % BN || a.K % BK || a.K / BK < 3 || a.K > 1024) return false;
     if (a.amap || a.cmap || a.c2map || a.splits > 1) return false;
     // The launch has to fill (most of) one round of 256 x 256 tiles over the CUs: below that the 160 x 256 kernel's smaller tiles keep
@@ -322,5 +345,6 @@ hipError_t launch_gemm_huge(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
         return launch_huge_t<EPI_OP>(a, max_blocks, s);
     }
     if (epi == EPI_GELU) return a.C2 ? launch_huge_t<EPI_GELU_C2>(a, max_blocks, s) : launch_huge_t<EPI_GELU>(a, max_blocks, s);
+    if (epi == EPI_GELU_BWD) return launch_huge_t<EPI_DGELU>(a, max_blocks, s);
     return hipErrorInvalidValue;
 }
