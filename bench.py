@@ -585,16 +585,32 @@ def main():
         alg_bytes = profiled.bytes / max(cnt["gemm"], 1)
         ms1, cnt1, gflops1 = profiled(run_one, [eng])
         executed = profiled.flops_all / nprof + non_gemm_flops_executed(cfg, a.views, a.classes) * a.updates
+        # pass C: the tile choices of a context that has the GPU to itself (ttl_ctx_set_concurrency(1)); the pipeline tells its
+        # contexts that a.streams episodes share the GPU, which moves the N = D projections to tiles that cost less CU-time and more
+        # makespan (csrc/gemm_huge.hip): passes A and B above run THOSE kernels, the ones of the timed region
+        alone = None
+        conc = getattr(eng, "concurrency", 1)
+        if conc > 1 and hasattr(eng, "set_concurrency"):
+            eng.set_concurrency(1)
+            msc, cntc, gflopsc = profiled(run_one, [eng])
+            eng.set_concurrency(conc)
+            achc = gflopsc / (msc["gemm"] * 1e-3) / 1e12
+            alone = {"achieved": round(achc, 1), "frac": round(achc / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(1e3 * msc["gemm"] / max(cntc["gemm"], 1), 2),
+                     "class_ms_per_image": {k: round(val / nprof, 3) for k, val in msc.items()},
+                     "note": "the same launches with the tile choices of a context that has the GPU to itself (ttl_ctx_set_concurrency(1): "
+                             "every N = D projection on gemm_big.hip's 160x256 tiles) — faster one at a time, slower in flight"}
         ach = gflops / (ms["gemm"] * 1e-3) / 1e12
         ach1 = gflops1 / (ms1["gemm"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach1, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_unit": "HBM-side bytes per GEMM launch",
                 "algorithmic_bytes_per_launch": round(alg_bytes),
                 "kernel": "gemm_big_kernel<5,3,EPI> (160x256x64 tiles, 8 waves, one persistent block per CU) + gemm_huge_kernel<EPI> (256x256x64, "
-                          "4 waves, LDS-DMA rings) for the q/k/v projection + gemm_kernel<160,2,2,2,EPI> "
+                          "4 waves, LDS-DMA rings) for the q/k/v projection and, in a context told that episodes run concurrently (the "
+                          "pipeline of the timed region), for the N = D projections (out_proj, fc2, their dgrads) + gemm_kernel<160,2,2,2,EPI> "
                           "for the MLP-dgrad / patch-embed epilogues: every big-M (M >= 1024) GEMM launch of an episode; the small-M "
                           "launches (1-view inference, CLS-row GEMMs of the last layer) are class gemm_small_m",
-                "regime": "one episode at a time (kernel alone on the chip; HIP events on the launch stream)",
+                "regime": "one episode at a time (kernel alone on the chip; HIP events on the launch stream), the kernels of the timed region",
+                "tile_choices_of_a_context_alone": alone,
                 "flops_per_launch": round(gflops1 / max(cnt1["gemm"], 1)),
                 "avg_launch_us": round(1e3 * ms1["gemm"] / max(cnt1["gemm"], 1), 2),
                 "launches_per_image": cnt1["gemm"] // nprof,

@@ -85,6 +85,12 @@ void ttl_ctx_destroy(ttl_ctx* ctx);
  * context is an error, and sharing FREEZES the parent's weights: ttl_load_weight on the parent fails with TTL_ESTATE while any
  * sharer is alive.  (ttl_workspace_bytes(cfg) is the footprint of an OWNING context; a sharing one allocates less.) */
 int ttl_ctx_create_shared(const ttl_config* cfg, ttl_ctx* parent, ttl_ctx** out);
+/* How many episodes the caller keeps in flight on this GPU (driver.EpisodePipeline: one context per HIP stream, default 1 = this
+ * context has the GPU to itself).  Results never depend on it; kernel tile choices may: with other episodes in flight the idle CUs of
+ * a partial round run their kernels, so a launch is chosen by its CU-time instead of its makespan (csrc/gemm_huge.hip: the N = D
+ * projections on 256 x 256 tiles, +2.5 % images/s at three episodes in flight, slower alone).  Takes effect for the launches (and
+ * graph captures) that follow. */
+int ttl_ctx_set_concurrency(ttl_ctx* ctx, int episodes_in_flight);
 
 /* Load one fp32 tensor of the HF vision tower by its state-dict name,
  * e.g. "vision_model.encoder.layers.3.mlp.fc1.weight", "visual_projection.weight".

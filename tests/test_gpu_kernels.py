@@ -325,6 +325,20 @@ def test_gemm_big_tiles_with_fused_epilogues(lib, prec, M, N, K, epi):
         assert (c[top:].float() == 7.0).all()
 
 
+def test_gemm_big_tile_epilogues_on_the_256x256_kernel(prec):
+    """The fp32-output / residual / operand-dtype epilogues of the N = D launches also exist on gemm_huge.hip (taken when the context
+    says that episodes run concurrently, ttl_ctx_set_concurrency): the kernel-level cases of test_gemm_big_tiles_with_fused_epilogues
+    again, in a child process that forces that kernel (TTL_GEMM_HUGE_NARROW=1: the switch is read once per process)."""
+    import os, subprocess, sys
+    if prec == "strict":
+        pytest.skip("the strict build has its own GEMM")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"), "-x", "-q", "-k",
+                          f"big_tiles_with_fused_epilogues and {prec}", "-p", "no:cacheprovider"],
+                         env=dict(os.environ, TTL_GEMM_HUGE_NARROW="1"), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_gemm_wide_fused_forms(lib, prec):
     """q/k/v head-major (modeling_clip.py:309-311 written as [view][plane][head][T][64]) and fc1 with both outputs (quick_gelu and
     the pre-activation the backward reads) through ttl_gemm_nt_fused — the forms no other kernel-level entry reaches — on both

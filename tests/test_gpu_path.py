@@ -510,6 +510,7 @@ def test_three_episodes_in_flight_are_bitwise_repeatable():
     x0 = torch.from_numpy(x).cuda()
     x1 = (torch.roll(x0, 3, dims=0) * 0.95).contiguous()
     eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0])
+    eng.set_concurrency(3)       # (the pipeline tells its contexts that three episodes share the GPU: same tile choices here)
     snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
     ref = [eng.episode(xx, snap, m, v, n_updates=1).clone() for xx in (x0, x1)]
     torch.cuda.synchronize()
@@ -943,3 +944,30 @@ def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objec
     else:       # every later step starts from the flipped elements of the one before: count those a tenth of a step (lr = 5e-3) apart
         bound(f"packed_backward/{name}/{objective}/{n_updates}/{precision}/frac_beyond_0.1lr", (d > 5e-4).mean(), 0.1)
     assert max_rel(res["1"]["l1"], res["0"]["l1"]) < (1e-4 if precision == "strict" else 5e-3)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_concurrency_hint_changes_tiles_not_results(precision):
+    """ttl_ctx_set_concurrency(>= 2) — what driver.EpisodePipeline tells its contexts — moves the N = D projections (out_proj, fc2, their
+    dgrads: fp32 outputs, residual epilogue) from gemm_big.hip's 160 x 256 tiles to gemm_huge.hip's 256 x 256 ones (CU-time instead of
+    makespan).  Same products, another tile shape and MFMA instruction: against the reference-written fixture the episode sits at the
+    same distances as the default tiling, and the two tilings agree with each other far inside those."""
+    g, cfg, W, x, lora0, tf = load_case("b16_n64_k200_ent0")
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for conc in (1, 3):
+        eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision=precision)
+        eng.set_concurrency(conc)
+        snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+        l1, l0 = eng.episode(xd, snap, m, v, n_updates=1, want_logits0=True)
+        torch.cuda.synchronize()
+        res[conc] = dict(l0=l0.cpu().numpy(), l1=l1.cpu().numpy(), grads=eng.grads.clone().cpu().numpy(), idx=np.sort(eng.last_selection(x.shape[0])[0]))
+        eng.close()
+    tol = 8e-3 if precision == "bf16" else 1e-3
+    for conc in (1, 3):
+        assert max_rel(res[conc]["l0"], g["logits0"]) < tol and max_rel(res[conc]["l1"], g["logits1"]) < tol * (1 if precision == "bf16" else 1.5)
+        assert np.array_equal(res[conc]["idx"], np.sort(np.asarray(g["idx"]).reshape(-1)))
+    # (on gfx950 the two kernels' fp32 sums over K come out bit-identical — v_mfma 16x16x32 and 32x32x16 accumulate the products of a
+    #  K range in one order — so these two bounds measure 0; they are bounds, not equalities, because nothing promises that)
+    bound(f"concurrency_tiles/{precision}/logits0", max_rel(res[3]["l0"], res[1]["l0"]), tol / 4)
+    bound(f"concurrency_tiles/{precision}/grads", max_rel(res[3]["grads"], res[1]["grads"]), 1e-2 if precision == "bf16" else 3e-3)

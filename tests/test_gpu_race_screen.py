@@ -20,6 +20,7 @@ def _screen(cfg, W, lora0, tf, batches, n_episodes, precision, lora_every=50, n_
     result bit for bit.  -> number of LoRA buffers compared."""
     from ttl_amd.driver import EpisodePipeline
     eng, flat, names = make_engine(cfg, W, lora0, tf, batches[0].shape[0], precision=precision)
+    eng.set_concurrency(n_streams)      # the tile choices of a context that shares the GPU (ttl_ctx_set_concurrency): the same kernels as the pipeline's
     snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
     ref_out, ref_lora = [], []
     for xb in batches:

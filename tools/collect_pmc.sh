@@ -5,6 +5,7 @@
 R=${1:-r05}
 P=${2:-fp16}
 export TTL_PRECISION=$P
+export TTL_CONCURRENCY=3      # quick_bench.py runs one stream: with the tile choices of the three-stream timed region (ttl_ctx_set_concurrency)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${R}_$P; mkdir -p $O
 # every pass under its own timeout: a counter set the hardware cannot collect makes rocprofv3 abort and then hang
 pass() { name=$1; shift; timeout 200 rocprofv3 --pmc "$@" -d $O/pmc_$name -o $name --output-format csv -- python3 tools/quick_bench.py > $O/pmc_$name.log 2>&1; echo "pass $name rc=$?"; }

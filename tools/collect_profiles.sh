@@ -14,7 +14,10 @@ O=gpurun_out/${R}_$P; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --streams 1 --no-cpu-baseline --no-parity --precision $P > $O/bench_streams1.json 2>> $O/bench.err
 Q="--no-cpu-baseline --no-parity --precision $P"
+# (TTL_CONCURRENCY=3: one stream, serialised by the profiler, with the tile choices of the three-stream timed region)
+export TTL_CONCURRENCY=3
 rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 $Q > $O/prof1.log 2>&1
+unset TTL_CONCURRENCY
 python3 bench.py --lora-targets qkvo $Q > $O/bench_qkvo.json 2>> $O/bench.err
 python3 bench.py --graph 0 $Q > $O/bench_graph0.json 2>> $O/bench.err
 python3 bench.py --classes 1000 $Q > $O/bench_k1000.json 2>> $O/bench.err

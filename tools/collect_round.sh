@@ -5,7 +5,9 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 bash tools/collect_profiles.sh r05 fp16 > gpurun_out/collect_fp16.log 2>&1
 bash tools/collect_pmc.sh r05 fp16 > gpurun_out/collect_pmc_fp16.log 2>&1
 O=gpurun_out/r05_bf16; mkdir -p $O
+export TTL_CONCURRENCY=3      # (the tile choices of the three-stream timed region, on one profiled stream)
 rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 --no-cpu-baseline --no-parity --precision bf16 > $O/prof1.log 2>&1
+unset TTL_CONCURRENCY
 python3 tools/trace_shapes.py $O/prof1/p1_kernel_trace.csv gemm > $O/prof1_gemm_shapes.txt 2>&1
 python3 tools/torch_stack_reference_point.py > gpurun_out/r05_fp16/torch_stack.json 2> gpurun_out/r05_fp16/torch_stack.err
 python3 tools/parity_per_fixture.py > gpurun_out/r05_fp16/parity_per_fixture.txt 2>&1

@@ -134,6 +134,7 @@ struct ttl_ctx {
     // runs with n = n_sel.  Image tower only.
     struct SelBuf { float *h_in, *h_mid, *lse, *mu1, *rs1, *mu2, *rs2; op_t *x1ext, *qkv, *attn, *u; };
     int sel_cap = 0, sel_rows = 0, cur_padded = 0;
+    int concurrency = 1;      // episodes the caller keeps in flight on this GPU (ttl_ctx_set_concurrency): GemmArgs::concurrent
     std::vector<SelBuf> selb;                  // one per saved layer (layer_lo .. L-1)
     float *sel_mean = nullptr, *sel_rstd = nullptr, *sel_y = nullptr, *sel_f = nullptr, *sel_h = nullptr, *sel_dz = nullptr;
     bool saved = false; int saved_n = 0; int stream_views = 0;
@@ -248,6 +249,7 @@ int gemm(ttl_ctx* c, GemmEpi epi, const GemmArgs& a0, hipStream_t s) {
     // (a backward on the packed views reads saved tensors that have sel_rows rows; its outputs are the full-size scratch buffers)
     a.padded = (a0.M > c->c.max_views) ? (c->cur_padded ? c->cur_padded : c->Mmax) : 0;
     a.ws = c->gemm_ws; a.ws_bytes = c->gemm_ws_bytes;
+    a.concurrent = c->concurrency;
     if (c->prof) c->gemm_flops_all += 2.0 * a.M * a.N * a.K;
     if (c->prof && big) {
         c->gemm_flops += 2.0 * a.M * a.N * a.K;
@@ -323,6 +325,11 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
         const char* v = getenv("TTL_QKV_HEAD_MAJOR");
         c->hm_magic = qkv_hm_magic((int)T, (int)M + 320);
         c->use_hm = (v ? atoi(v) != 0 : 1) && c->hm_magic != 0;
+    }
+    {   // TTL_CONCURRENCY: the default of ttl_ctx_set_concurrency for every context of the process (profiling a single stream with the
+        // kernels of the three-stream run)
+        const char* v = getenv("TTL_CONCURRENCY");
+        if (v && atoi(v) >= 1) c->concurrency = atoi(v);
     }
     c->layers.resize(c->L);
     for (int i = 0; i < c->L; ++i) {
@@ -1236,6 +1243,13 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
 int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
     if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_backward_lora on a text-tower context (use ttl_text_backward_lora)");
     return backward_impl(c, dlogits, n, stream);
+}
+
+int ttl_ctx_set_concurrency(ttl_ctx* c, int episodes_in_flight) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    if (episodes_in_flight < 1) return fail(TTL_EINVAL, "episodes_in_flight must be >= 1");
+    c->concurrency = episodes_in_flight;
+    return 0;
 }
 
 int ttl_vit_backward_lora_selected(ttl_ctx* c, const float* dlogits, int n, const int64_t* idx, int n_selected, void* stream) {

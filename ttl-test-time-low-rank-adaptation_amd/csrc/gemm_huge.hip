@@ -27,7 +27,11 @@
 //     accumulators' initial value; persistent tile loop, the next tile's bias and first K-tiles requested before the last 16 MFMAs
 //     and the stores of the current one
 //   * stores through buffer descriptors: rows >= M are dropped by the range check (no padding requirement on the outputs)
-//   * taken only when the launch has tiles for >= 85 % of the CUs (gemm_huge_applicable)
+//   * q/k/v: taken when the launch has tiles for >= 85 % of the CUs (gemm_huge_applicable)
+//   * the N = D projections (out_proj, fc2 and their dgrads: EPI_RESID_F32 / EPI_F32 / EPI_OP, 150 tiles at 64 views): taken when
+//     the context was told that other episodes share the GPU (GemmArgs::concurrent >= 2, ttl_ctx_set_concurrency) and the launch has
+//     tiles for half of the CUs: 72 us against 60.5 us one at a time, 10.8 against 14.3 ms of CU-time, +2.5 % images/s with three
+//     episodes in flight.  The residual tile is folded into the accumulators' initial value in two halves of 32 rows.
 // History of the design (first cut with compiler-scheduled register staging 106 us, hand-pipelined register staging 57-60 us, all-DMA
 // with bunched requests 56 us): profiles/r05_experiments.txt r05l, r05n.
 #include <stdlib.h>
@@ -108,8 +112,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, RSRC);
     // outputs: rows >= M lie past num_records (row-major) or get an out-of-range offset (head-major) and are dropped
     // (head-major: whole [T][64] tiles of ceil(M / T) views — a trailing partial view's rows lie inside its own view block)
+    constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_RESID_F32);
+    constexpr int ESZ = F32OUT ? 4 : (int)sizeof(op_t);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-        a.C, 0, (int)(EPI == EPI_OP_HM ? (size_t)((M + a.hm_T - 1) / a.hm_T) * a.hm_T * a.N * sizeof(op_t) : (size_t)M * a.ldc * sizeof(op_t)), RSRC);
+        a.C, 0, (int)(EPI == EPI_OP_HM ? (size_t)((M + a.hm_T - 1) / a.hm_T) * a.hm_T * a.N * sizeof(op_t) : (size_t)M * a.ldc * ESZ), RSRC);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0, (int)(EPI == EPI_RESID_F32 ? (size_t)M * a.ldr * 4 : 0), RSRC);
     const __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.C2, 0, (int)(EPI == EPI_GELU_C2 ? (size_t)M * a.ldc2 * sizeof(op_t) : 0), RSRC);
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, (int)(EPI == EPI_DGELU ? (size_t)M * a.ldaux * sizeof(op_t) : 0), RSRC);
     const int voA = (int)((r8 * a.lda + cs * 8) * sizeof(op_t));
@@ -163,21 +170,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (;;) {
         // K-tile 0 of A and B and the bias have landed; K-tile 1 of A may still fly.  Behind a previous tile its 64 (GELU + u: 128)
         // stores and K-tile 1 are younger than what is waited for: vmcnt counts loads and stores together, in order, up to 63
+        // residual tile (EPI_RESID_F32), folded into the accumulators' initial value in two halves of 32 rows x 4 columns per lane: the first
+        // half is requested here, under the wait for K-tile 0, the second behind the requests of step 0
+        [[maybe_unused]] f32x4 rs[2][16];
+        [[maybe_unused]] const int voR = (int)(((wm * 128 + 4 * lh) * a.ldr + wn * 128 + 4 * l32) * 4);
+        auto ld_res = [&](int g) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rs[h][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsR, voR, (int)(((size_t)(row0 + (2 * g + h) * 32 + 8 * (r >> 2) + (r & 3)) * a.ldr + col0) * 4), 0));
+        };
+        if constexpr (EPI == EPI_RESID_F32) ld_res(0);
         if (first) wait_vm<8>(); else wait_vm<63>();
         __builtin_amdgcn_s_barrier();
         char *aC = A0, *aN = A0 + SLOT, *aNN = A0 + 2 * SLOT, *bC = B0, *bN = B0 + SLOT;
         auto rotate = [&]() { char* t = aC; aC = aN; aN = aNN; aNN = t; t = bC; bC = bN; bN = t; };
+        [[maybe_unused]] f32x4 resid_bv = {0.f, 0.f, 0.f, 0.f};
         {   // the bias leaves the third slot before K-tile 2 is requested into it (one extra barrier per tile)
             const f32x4 bv = *(const f32x4*)(aNN + (wn * 128 + 4 * l32) * 4);
             frags(aC, bC, 0, 0);
             wait_vm<63>();
             __builtin_amdgcn_s_barrier();
+            if constexpr (EPI != EPI_RESID_F32) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][j][r] = bv[j];
+                        for (int r = 0; r < 16; ++r) acc[mt][j][r] = bv[j];
+            } else {
+                auto init_half = [&](int g) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[2 * g + h][j][r] = bv[j] + rs[h][r][j];
+                };
+                init_half(0);
+                resid_bv = bv;
+            }
         }
         // one K-step.  front: the body starts with sub-step 3 of K-tile kt-1 (not for kt = 0); hb / ha: K-tiles kt+1 (B) / kt+2 (A) exist
         auto body = [&](int kt, auto hb_, auto ha_, auto front_) {
@@ -189,6 +223,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 mix<hb ? 4 : 0>();
             } else {
                 if constexpr (hb) dma_b(bN, col0, kt + 1, 0, 4);
+                if constexpr (EPI == EPI_RESID_F32) {      // step 0: the second half of the residual tile behind the first requests
+                    ld_res(1);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[2 + h][j][r] = resid_bv[j] + rs[h][r][j];
+                }
             }
             frags(aC, bC, 1, 1);
             if constexpr (hb) dma_b(bN, col0, kt + 1, 4, 8);
@@ -244,7 +287,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int rem = n0 - plane * Dm;
             vo = (plane * Dm + (rem & ~63)) * a.hm_T + (rem & 63);
         } else {
-            vo = (int)(((wm * 128 + 4 * lh) * a.ldc + wn * 128 + 4 * l32) * sizeof(op_t));
+            vo = (int)(((wm * 128 + 4 * lh) * a.ldc + wn * 128 + 4 * l32) * ESZ);
             if constexpr (EPI == EPI_GELU_C2) vo2 = (int)(((wm * 128 + 4 * lh) * a.ldc2 + wn * 128 + 4 * l32) * sizeof(op_t));
         }
 #pragma unroll
@@ -259,6 +302,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     const unsigned view = __umulhi(m, a.hm_magic), t = m - view * (unsigned)a.hm_T;
                     const unsigned off = (view * (unsigned)a.N * (unsigned)a.hm_T + (unsigned)vo + t * 64u) * (unsigned)sizeof(op_t);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, rsC, (int)(m < (unsigned)M ? off : 0x80000000u), 0, 0);
+                } else if constexpr (F32OUT) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v0, v1, v2, v3}), rsC, vo,
+                                                           (int)(((size_t)(row0 + mrow) * a.ldc + col0) * 4), 0);
                 } else {
                     if constexpr (EPI == EPI_GELU_C2)
                         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_op2(v0, v1), pack_op2(v2, v3)}, rsC2, vo2,
@@ -310,6 +356,23 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // its u tile has to be read behind the last MFMAs, profiles/r05_experiments.txt r05q): off
     static const int dgrad = [] { const char* v = getenv("TTL_GEMM_HUGE_DGRAD"); return v ? atoi(v) : 0; }();
     if (mode <= 0) return false;
+    // The N = 768 / 1024 launches (out_proj, fc2 and their dgrads: fp32 outputs, residual): 150 tiles of 256 x 256 leave 106 CUs idle and
+    // take 40 % longer than the 160 x 256 kernel's 237 tiles one at a time — but 11-31 % less CU-time, and with other episodes in flight
+    // (GemmArgs::concurrent >= 2: the caller said so, ttl_ctx_set_concurrency) those CUs run their kernels: +2.5 % images/s at three
+    // episodes in flight, +1.1 % at two; below tiles for half of the CUs it loses (32 views: -1 %, 8 views: -8 %).
+    // TTL_GEMM_HUGE_NARROW: -1 = that rule (default), 0 = never, 1 = whenever the launch has the tiles.  profiles/r05_narrow_ab_fp16.txt
+    static const int narrow = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW"); return v ? atoi(v) : -1; }();
+    if ((epi == EPI_F32 || epi == EPI_RESID_F32 || epi == EPI_OP) && !a.hm_T && a.N < 2304) {
+        if (narrow == 0 || (narrow < 0 && a.concurrent < 2)) return false;
+        if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3 || a.amap || a.cmap || a.c2map || a.splits > 1) return false;
+        const size_t lim2 = (size_t)1 << 31;
+        if ((size_t)a.M * a.lda * sizeof(op_t) >= lim2 || (size_t)a.N * a.ldb * sizeof(op_t) >= lim2 || (size_t)a.M * a.ldc * 4 >= lim2) return false;
+        if (epi == EPI_RESID_F32 && (!a.resid || (size_t)a.M * a.ldr * 4 >= lim2)) return false;
+        static const int mink = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW_MINK"); return v ? atoi(v) : 0; }();
+        static const int maxk = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW_MAXK"); return v ? atoi(v) : 1 << 30; }();
+        const long cus2 = device_cu_count();
+        return cus2 > 0 && (long)((a.M + BM - 1) / BM) * (a.N / BN) * 2 >= cus2 && a.K >= mink && a.K <= maxk;
+    }
     if (epi == EPI_GELU_BWD) { if (!dgrad || !a.aux || (size_t)a.M * a.ldaux * sizeof(op_t) >= ((size_t)1 << 31)) return false; }
     else if (epi != EPI_OP && epi != EPI_GELU) return false;
     else if ((mode == 2 && epi != EPI_OP) || (mode == 3 && epi != EPI_GELU)) return false;
@@ -346,5 +409,7 @@ hipError_t launch_gemm_huge(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
     }
     if (epi == EPI_GELU) return a.C2 ? launch_huge_t<EPI_GELU_C2>(a, max_blocks, s) : launch_huge_t<EPI_GELU>(a, max_blocks, s);
     if (epi == EPI_GELU_BWD) return launch_huge_t<EPI_DGELU>(a, max_blocks, s);
+    if (epi == EPI_F32) return launch_huge_t<EPI_F32>(a, max_blocks, s);
+    if (epi == EPI_RESID_F32) return launch_huge_t<EPI_RESID_F32>(a, max_blocks, s);
     return hipErrorInvalidValue;
 }

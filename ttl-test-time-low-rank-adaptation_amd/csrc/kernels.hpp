@@ -72,6 +72,9 @@ struct GemmArgs {
     // c = plane*D + head*64 + d (D = N/3) goes to C[view*3*D*hm_T + plane*D*hm_T + head*64*hm_T + t*64 + d]: every (view, plane,
     // head) is one contiguous [T][64] tile, which is what the attention kernels stage (QkvLayout below).  hm_magic: see qkv_hm_magic.
     int hm_T; unsigned hm_magic;
+    // Episodes sharing the GPU with this launch's stream (ttl_ctx_set_concurrency; 0 / 1: alone).  With others in flight the idle CUs of a
+    // partial round run their kernels, so a launch costs its CU-time, not its makespan: the tile choice may differ (gemm_huge_applicable).
+    int concurrent;
 };
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // gemm_big.hip: (32*MT) x 256 tiles, 8 waves, one persistent block per CU; big-M launches whose output buffers have

@@ -418,6 +418,14 @@ class EpisodePipeline:
                                    stream=torch.cuda.Stream(device=dev, priority=prios[len(self.slots) % len(prios)]) if prios
                                    else torch.cuda.Stream(device=dev),
                                    acc=torch.zeros(3, dtype=torch.int64, device=dev)))   # [hits1, hits5, count]
+        # every context learns how many episodes share the GPU: with others in flight a GEMM launch is chosen by its CU-time, not its
+        # makespan (include/ttl_hip.h ttl_ctx_set_concurrency; text mode: both towers)
+        # (TTL_CONCURRENCY: profiling runs replay ONE stream with the kernels the three-stream run picks)
+        self.concurrency = max(len(self.slots), int(os.environ.get("TTL_CONCURRENCY", "0") or 0))
+        for sl in self.slots:
+            for e in (sl["eng"], getattr(sl["eng"], "img", None), getattr(sl["eng"], "txt", None)):
+                if e is not None and hasattr(e, "set_concurrency"):
+                    e.set_concurrency(self.concurrency)
         self._next = 0
         self._text_features, self._logit_scale, self._text_version = text_features, logit_scale_exp, 0     # (for the PLPD auxiliary contexts)
         # use_graph: every slot replays its episode as ONE hipGraphLaunch (captured on first use per argument set)
@@ -469,6 +477,7 @@ class EpisodePipeline:
                 aux = sl["aux"] = TTLEngine(eng.cfg, eng.max_views, eng.max_classes, eng.device, eng.precision,
                                             share_from=self.slots[0]["eng"])          # (slot 0 owns its weight images)
                 aux.bind_lora(sl["flat"])
+                aux.set_concurrency(self.concurrency)
                 sl["aux_classes"] = None
             if sl.get("aux_classes") != self._text_version:
                 aux.set_text_features(self._text_features, self._logit_scale)

@@ -248,6 +248,12 @@ class TTLEngine:
             self._check(self.lib.ttl_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, betas[0],
                                                betas[1], eps, weight_decay, int(step), _ptr(n_selected), _stream()))
 
+    def set_concurrency(self, episodes_in_flight: int):
+        """Tell the context how many episodes share the GPU (driver.EpisodePipeline does: one context per stream).  Results do not
+        depend on it; tile choices do (include/ttl_hip.h ttl_ctx_set_concurrency)."""
+        self._check(self.lib.ttl_ctx_set_concurrency(self._h, int(episodes_in_flight)))
+        self.concurrency = int(episodes_in_flight)
+
     # ---- GradScaler contract (ttl.py:222, deyo.py:186-188): state on the device, see include/ttl_hip.h
     def scaler_config(self, dynamic=True, init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self._check(self.lib.ttl_scaler_config(self._h, int(bool(dynamic)), float(init_scale), float(growth_factor),
