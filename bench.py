@@ -63,6 +63,12 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity check against the reference-generated fixture")
     ap.add_argument("--variant-lib", action="store_true", help="allow TTL_HIP_LIB_BF16 / TTL_HIP_LIB_FP16 to swap in another build of the "
                     "library (A/B tools); without it such an override is refused, and the line always records path + sha256 of what ran")
+    ap.add_argument("--variant-env", action="store_true", help="allow a run-time kernel switch of the library (ttl_runtime_switches: TTL_GEMM_HUGE, "
+                    "TTL_GEMM_HUGE_NARROW, TTL_GEMM_HUGE_MIN_FILL, TTL_BWD_COMPACT, TTL_CONCURRENCY) to be off its default; without it such a run "
+                    "is refused.  The line records every switch under protocol.kernel_env either way")
+    ap.add_argument("--sustain-seconds", type=float, default=-1.0, help="after the interleaved timed blocks the headline leg runs this long "
+                    "WITHOUT a fence in between (BASELINE config 3 is 170 s of continuous load; the timed blocks are 1.5 s): reported under "
+                    "`sustained`, never `value`.  Default: 30 with --gpus 1, 0 (off) otherwise")
     ap.add_argument("--strict-balance", action="store_true", help="N > 1: exit non-zero when the slowest rank is > 10 %% under the median "
                     "rank (the line carries rank_balance either way)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -76,8 +82,11 @@ def parse_args():
     a = ap.parse_args()
     if a.precision is None:
         a.precision = "auto" if a.gpus <= 1 else "fp16"
+    if a.sustain_seconds < 0:
+        a.sustain_seconds = 30.0 if a.gpus <= 1 else 0.0
     if a.stub_pipeline:
         a.backend, a.no_parity, a.no_cpu_baseline, a.no_pin = "gloo", True, True, True
+        a.sustain_seconds = min(a.sustain_seconds, 0.3)
     return a
 
 
@@ -200,8 +209,18 @@ def cpu_baseline(cfg, n_classes, full_views=64, budget_s=30.0):
     return out
 
 
-def parity_check(precision):
-    """Untimed: the reference-generated fixture b16_n64_k200_ent0 (ViT-B/16, 64 views, K=200: the benched workload's
+# Which committed fixtures decide "this build conforms" (headline_rule): every reference-written ViT-B/16 fixture of ONE optimizer update
+# with the benched adapter set (q_proj + v_proj) on the benched weights — the benched shape (64 views, K = 200) under all three
+# objectives (every view, top-rho, TPT), K = 1000 under both selections, and BASELINE config 1's 8 views / K = 10.  The first one is
+# the benched workload itself and fills `parity`; the others are listed under parity.fixtures.  PARITY_OTHERS are reported the same
+# way but do NOT decide (CLIP-like activation outliers, the north_star's q/k/v/out adapter set: the fp16 build sits at 1.1e-3 /
+# 1.9e-3 adapted logits there — VERDICT r05 What's weak 3 — and the line says so instead of hiding it).
+PARITY_DECIDE = ("b16_n64_k200_ent0", "b16_n64_k200_ent1", "b16_n64_k200_tpt", "b16_n64_k1000_ent0", "b16_n64_k1000_ent1", "b16_n8_k10")
+PARITY_OTHERS = ("b16_n64_k200_qkvo", "b16_n8_k10_qkvo", "b16_n64_k200_outliers", "b16_n8_k10_outliers")
+
+
+def parity_check(precision, fixture="b16_n64_k200_ent0"):
+    """Untimed: a reference-generated fixture (default b16_n64_k200_ent0: ViT-B/16, 64 views, K=200, the benched workload's
     shape) through the build for `precision`.  metric = max|a-b| / max|b| per tensor (tests/helpers.max_rel).
     precision == "strict": the test-only fp32 build (libttl_hip_strict.so: same launch sequences, LayerNorm / head / loss /
     optimizer kernels; fp32 products) held to the tolerance BY THE LETTER — logits 1e-5, every gradient tensor 1e-4, post-step
@@ -211,7 +230,7 @@ def parity_check(precision):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import load_case, episode_kwargs, max_rel
     from ttl_amd.engine import TTLEngine
-    g, cfg, W, x, lora0, tf = load_case("b16_n64_k200_ent0")
+    g, cfg, W, x, lora0, tf = load_case(fixture)
     kw = episode_kwargs(g)
     from ttl_amd.config import trainable_names
     names = trainable_names(cfg)
@@ -263,7 +282,7 @@ def parity_check(precision):
     le, ae = max_rel(l0.cpu().numpy(), g["logits0"]), max_rel(l1.cpu().numpy(), g["logits1"])
     mask = bool(np.array_equal(np.sort(idx), np.sort(np.asarray(g["idx"]).reshape(-1))))
     wfro = (dn2 / max(rn2, 1e-300)) ** 0.5
-    out = {"fixture": "tests/golden/b16_n64_k200_ent0.npz (written by the reference's own test_time_tuning, fp32 CPU)",
+    out = {"fixture": f"tests/golden/{fixture}.npz (written by the reference's own test_time_tuning, fp32 CPU)",
            "dtype": precision, "metric": "max|a-b|/max|b| per tensor",
            "logits_max_rel": round(le, 6), "adapted_logits_max_rel": round(ae, 6),
            "grad_max_rel": round(gerr, 6), "grad_rel_frobenius": round((dg2 / max(rg2, 1e-300)) ** 0.5, 6),
@@ -429,24 +448,57 @@ def main():
 
     # the legs: BOTH operand builds under one protocol (auto), or the one asked for.  The conforming build comes first.
     legs = ["fp16", "bf16"] if a.precision == "auto" else [a.precision]
-    ident = {p: ({"lib_path": "stub (--stub-pipeline)", "lib_sha256_16": None} if stub else lib_identity(p)) for p in legs}
+    ident = {p: ({"lib_path": "stub (--stub-pipeline)", "lib_sha256_16": "0" * 16} if stub else lib_identity(p)) for p in legs}
+    if stub and os.environ.get("TTL_BENCH_STUB_LIBSHA", "").split(":")[0] == str(rank):       # test hook: this rank "loaded" another file
+        ident = {p: dict(ident[p], lib_sha256_16=os.environ["TTL_BENCH_STUB_LIBSHA"].split(":")[1]) for p in legs}
+    # N ranks on one checkout must have loaded the SAME file (8 ranks with 8 stale .so copies is the classic first-run failure):
+    # every rank's sha256[:16] of every leg's library rides the accumulator's collective; a mismatch ends the run
+    lib_per_rank = {}
+    for p in legs:
+        mine = torch.tensor([int(ident[p]["lib_sha256_16"][:15], 16)], dtype=torch.int64, device=dev)      # (15 hex digits: fits int64)
+        rows = shard.gather(mine).reshape(-1).tolist()
+        lib_per_rank[p] = [f"{int(v):015x}" for v in rows]
+        if len(set(lib_per_rank[p])) != 1:
+            raise SystemExit(f"the ranks loaded different {p} libraries (sha256[:15] per rank: {lib_per_rank[p]}): rebuild, then run again")
 
-    # ---- untimed parity of every leg against the reference-generated fixture (rank 0; decides the headline in auto mode)
+    # ---- the library's run-time kernel switches (ttl_runtime_switches): recorded, and a non-default one is refused
+    kernel_env = {}
+    if not stub:
+        from ttl_amd import _lib
+        for p in legs:
+            kernel_env[p] = {k: {"value": v[0], "default": v[1]} for k, v in _lib.runtime_switches(p).items()}
+        off = sorted({f"{k}={v['value']} (default {v['default']})" for p in legs for k, v in kernel_env[p].items() if v["value"] != v["default"]})
+        if off and not a.variant_env:
+            raise SystemExit(f"{', '.join(off)} would change the kernel path under the bench: pass --variant-env if that is intended")
+
+    # ---- untimed parity of every leg against the reference-generated fixtures (rank 0; decides the headline in auto mode)
     parity = {}
     if rank == 0 and not a.no_parity and cfg.name == "ViT-B/16":
-        for p in legs:
-            try:
-                parity[p] = parity_check(p)
-            except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
-                parity[p] = {"error": f"{type(e).__name__}: {e}"}
-        try:                            # the test-only fp32 build on the same fixture (never timed)
-            parity["strict"] = parity_check("strict")
-        except Exception as e:
-            parity["strict"] = {"error": f"{type(e).__name__}: {e}"}
+        def brief(r):
+            if "error" in r:
+                return r
+            m = r["meets_north_star_tolerance"]
+            return {"logits_max_rel": r["logits_max_rel"], "adapted_logits_max_rel": r["adapted_logits_max_rel"], "grad_max_rel": r["grad_max_rel"],
+                    "lora_weights_rel_frobenius": r["lora_weights_rel_frobenius"], "mask_exact": r["mask_exact"], "top1_equal": r["top1_equal"],
+                    "selection_mask_and_logits_within_tolerance": bool(m["selection_mask"] and m["logits"])}
+        for p in legs + ["strict"]:     # (strict: the test-only fp32 build on the same fixtures, never timed)
+            per = {}
+            for fx in PARITY_DECIDE + PARITY_OTHERS:
+                try:
+                    r = parity_check(p, fx)
+                except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
+                    r = {"error": f"{type(e).__name__}: {e}"}
+                if fx == PARITY_DECIDE[0]:
+                    parity[p] = r
+                per[fx] = brief(r)
+            ok = lambda fx: bool(per[fx].get("selection_mask_and_logits_within_tolerance"))
+            parity[p]["fixtures"] = per
+            parity[p]["fixtures_deciding"] = list(PARITY_DECIDE)
+            parity[p]["conforms_on_every_deciding_fixture"] = all(ok(fx) for fx in PARITY_DECIDE)
+            parity[p]["fixtures_outside_tolerance"] = [fx for fx in PARITY_DECIDE + PARITY_OTHERS if not ok(fx)]
 
     def conforms(p):
-        m = parity.get(p, {}).get("meets_north_star_tolerance")
-        return bool(m and m["selection_mask"] and m["logits"])
+        return bool(parity.get(p, {}).get("conforms_on_every_deciding_fixture"))
 
     def fence(pipe):
         """-> seconds until THIS rank's streams were drained (before the barrier the other ranks join)"""
@@ -538,6 +590,69 @@ def main():
         return out
 
     numbers = {p: leg_numbers(p) for p in legs}
+
+    def read_sclk():
+        """Current shader clock (MHz) of this rank's GPU from sysfs, best effort (None when the node is not readable)."""
+        import glob
+        import re
+        out = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            try:
+                cur = [l for l in open(f).read().splitlines() if l.rstrip().endswith("*")]
+                m = re.search(r"(\d+)\s*Mhz", cur[0], re.I) if cur else None
+                out.append(int(m.group(1)) if m else None)
+            except Exception:
+                out.append(None)
+        return out or None
+
+    def sustained_run(pipe, seconds):
+        """The same pipeline, `seconds` of continuous load with NO fence inside (what a 50 000-image evaluation looks like; the timed
+        blocks above are 23 x 67 ms with a drain after each): chunks of --steps images are enqueued back to back, an event per slot
+        stream marks the end of every chunk on the GPU's own timeline, the host only waits for the chunk two behind (bounded run-ahead)."""
+        chunk = max(a.steps, 1)
+        fence(pipe)
+        sclk0 = read_sclk()
+        marks, i0 = [], 0
+        start = [torch.cuda.Event(enable_timing=True) for _ in pipe.slots]
+        for ev, sl in zip(start, pipe.slots):
+            ev.record(sl["stream"])
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for i in range(i0, i0 + chunk):
+                pipe.submit(pool[item(i)], target=labels[item(i)], persistent_input=True, want_output=False, n_updates=a.updates, **sel_kw)
+            i0 += chunk
+            evs = [torch.cuda.Event(enable_timing=True) for _ in pipe.slots]
+            for ev, sl in zip(evs, pipe.slots):
+                ev.record(sl["stream"])
+            marks.append(evs)
+            if len(marks) > 2:
+                for ev in marks[-3]:
+                    ev.synchronize()
+        pipe.synchronize()
+        wall = time.perf_counter() - t0
+        sclk1 = read_sclk()
+        # GPU-side completion time of every chunk (max over the slot streams), seconds from the common start
+        done = [max(s_.elapsed_time(e_) for s_, e_ in zip(start, evs)) * 1e-3 for evs in marks]
+        total = done[-1]
+        tail_from = max(total - 20.0, 0.0)
+        k0 = next(j for j, t in enumerate(done) if t >= tail_from)      # chunks finished inside the last 20 s
+        n_tail = (len(done) - 1 - k0) * chunk
+        v_tail = n_tail / max(done[-1] - done[k0], 1e-9) if n_tail > 0 else i0 / total
+        head = [chunk * (j + 1) / t for j, t in enumerate(done) if t <= 5.0]
+        return {"seconds": round(total, 2), "host_wall_seconds": round(wall, 2), "images": i0, "value": round(i0 / total, 2),
+                "value_last_20s": round(v_tail, 2), "value_first_5s": round(head[-1], 2) if head else None,
+                "sclk_mhz_before": sclk0, "sclk_mhz_after": sclk1, "chunk_images": chunk,
+                "note": "headline leg, same pipeline and inputs, no fence between images; GPU-side chunk timestamps (HIP events on the slot streams)"}
+
+    sustained = None
+    head_pre = next((p for p in legs if conforms(p)), legs[0])      # (the headline leg is known before the timing: parity ran first)
+    if a.sustain_seconds > 0 and world == 1 and not stub:
+        try:
+            sustained = sustained_run(pipes[head_pre], a.sustain_seconds)
+            sustained["dtype"] = head_pre
+            sustained["ratio_to_value"] = round(sustained["value_last_20s"] / numbers[head_pre]["value"], 4)
+        except Exception as e:      # never let the secondary figure break the bench line
+            sustained = {"error": f"{type(e).__name__}: {e}"}
     acc = {p: shard.accuracy(pipes[p].totals()) for p in legs}   # C1: accuracy accumulator of the LAST timed block (the path's only collective)
     graph_per_rank = None
     if world > 1:
@@ -671,8 +786,13 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": n["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": head, "dtype_note": notes[head], "data": "synthetic",
-            "headline_rule": "the first of [fp16, bf16] operand builds whose measured parity (`parity`) meets the north_star's selection-mask "
-                             "and logit tolerance; every build timed is listed under `legs`, all under ONE protocol (`protocol`)",
+            "headline_rule": "the first of [fp16, bf16] operand builds whose measured parity meets the north_star's selection-mask and logit "
+                             "tolerance (mask exact, first-forward and adapted logits <= 1e-3) on EVERY deciding fixture — the committed "
+                             "reference-written ViT-B/16 fixtures of one update with the benched adapter set and weights: "
+                             + ", ".join(PARITY_DECIDE) + " — the first being the benched workload (`parity`); parity.fixtures also lists "
+                             "the fixtures that do not decide (" + ", ".join(PARITY_OTHERS) + ") and parity.fixtures_outside_tolerance names "
+                             "every fixture, deciding or not, on which the build is outside 1e-3; every build timed is listed under `legs`, "
+                             "all under ONE protocol (`protocol`)",
             "value_conforming": value if conforms(head) else None, "dtype_conforming": head if conforms(head) else None,
             "repeats": n["repeats"], "value_min": n["value_min"], "value_max": n["value_max"], "value_iqr": n["value_iqr"],
             "value_note": "median of `repeats` timed blocks of `steps` steps per rank each (every block: barrier + synchronize on both "
@@ -680,7 +800,10 @@ def main():
             "host_enqueue_ms_per_image": n["host_enqueue_ms_per_image"],
             "lib_path": n["lib_path"], "lib_sha256_16": n["lib_sha256_16"],
             "protocol": {"steps": a.steps, "warmup": a.warmup, "repeats": n["repeats"], "hip_graph": use_graph, "hip_graph_reason": why,
-                         "legs": legs, "interleaved_blocks": len(legs) > 1, "variant_lib_env": overrides},
+                         "legs": legs, "interleaved_blocks": len(legs) > 1, "variant_lib_env": overrides,
+                         "kernel_env": kernel_env.get(head), "kernel_env_all_default": all(v["value"] == v["default"] for p in kernel_env for v in kernel_env[p].values()),
+                         "lib_sha256_15_per_rank": lib_per_rank.get(head),
+                         "order": "parity (untimed) -> warm-up -> interleaved timed blocks -> sustained run -> roofline passes -> CPU baseline"},
             "config": {"workload": f"{cfg.name} r={cfg.rank}, adapters on {tg}, {a.views} views, {a.updates} TTA step, K={a.classes} "
                                    f"(ImageNet-A shape), {sel_text}layers {cfg.layer_lo}-{cfg.layer_hi}, episodic reset + adapted "
                                    f"1-view inference; views pre-staged in HBM; {a.steps} images/rank per timed block",
@@ -698,7 +821,21 @@ def main():
                                      "note": "synthetic labels: exercises the sharded accumulator + all-reduce, not a quality number; "
                                              "no pretrained checkpoint / dataset exists offline, so README top-1 is not reproducible here"},
             "roofline": roofs.get(head),
+            "sustained": sustained,
         }
+        # the same GPU driven by the stock torch stack (HF CLIP + peft-style LoRA under autocast fp16, tools/torch_stack_reference_point.py):
+        # a STATIC read of the committed measurement, the meaningful context beside the CPU baseline
+        try:
+            import glob as _glob
+            src = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_torch_stack_reference_point.json")))[-1]
+            tj = json.load(open(src))
+            out["torch_stack_same_gpu"] = {"value": tj["images_per_sec"], "unit": "images/sec", "static": True, "source": "profiles/" + os.path.basename(src),
+                                           "measured": time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(src))), "stack": tj.get("stack"),
+                                           "views": tj.get("views"), "classes": tj.get("classes"),
+                                           "ratio": round(value / tj["images_per_sec"], 2) if (world == 1 and a.views == tj.get("views")) else None,
+                                           "note": "not measured in this run: the reference's own software stack on one MI355X, class-text features cached"}
+        except Exception:
+            pass
         if world > 1:
             out["per_rank_value"] = n["per_rank_value"]
             out["rank_balance"] = n["rank_balance"]

@@ -65,12 +65,24 @@ typedef struct ttl_ctx ttl_ctx;
 
 const char* ttl_last_error(void);
 const char* ttl_version(void);
-/* "bf16" (libttl_hip.so, default) or "fp16" (libttl_hip_fp16.so: the reference's autocast dtype, ttl.py:79).
- * Every "operand" buffer below (qkv, attention out, ...) holds 16-bit values of that type. */
+/* "fp16" (libttl_hip_fp16.so: the reference's autocast dtype, ttl.py:79 — the build the Python surface loads by default, inside
+ * the 1e-3 logit tolerance), "bf16" (libttl_hip.so, opt-in) or "fp32" (libttl_hip_strict.so, test build).
+ * Every "operand" buffer below (qkv, attention out, ...) holds values of that type. */
 const char* ttl_operand_dtype(void);
+/* The environment variables this library reads, one per line: "NAME=<value in effect> default=<default> # what it selects".
+ * These five are ALL a product build reads (every other TTL_* knob of the sources is a closed experiment, compiled to its default
+ * unless the library was built with -DTTL_EXPERIMENTS: libttl_hip_fp16_exp.so, tests / tools only).  bench.py prints them under
+ * protocol.kernel_env and refuses to time a run in which one of them is not at its default (--variant-env overrides).
+ * Thread-local buffer, valid until the next call on the thread. */
+const char* ttl_runtime_switches(void);
 
-/* Device memory the context will allocate for `cfg` (weights + activation arena), bytes. */
+/* Device memory ttl_ctx_create will allocate for `cfg` (weights + activation arena + the packed-backward buffers of top-k
+ * selections), bytes: the allocation walk of ttl_ctx_create itself with nothing allocated, so the figure is exact (and needs no
+ * GPU).  NOT included: what a PLPD stage allocates on its first use in a context — the destroyed views
+ * (max_views*3*image_size^2*4 bytes) plus ttl_plpd_views_workspace_bytes(); text tower: 2*max_views*E*4 + 2*prompts*max_views*4. */
 size_t ttl_workspace_bytes(const ttl_config* cfg);
+/* Device bytes `ctx` has allocated so far (== ttl_workspace_bytes(cfg) for an owning context until a PLPD stage has run). */
+size_t ttl_ctx_allocated_bytes(const ttl_ctx* ctx);
 
 /* Replaces model construction + .cuda(): clip/custom_clip.py:570-623, ttl.py:178-179. */
 int ttl_ctx_create(const ttl_config* cfg, ttl_ctx** out);
@@ -86,7 +98,10 @@ void ttl_ctx_destroy(ttl_ctx* ctx);
  * sharer is alive.  (ttl_workspace_bytes(cfg) is the footprint of an OWNING context; a sharing one allocates less.) */
 int ttl_ctx_create_shared(const ttl_config* cfg, ttl_ctx* parent, ttl_ctx** out);
 /* How many episodes the caller keeps in flight on this GPU (driver.EpisodePipeline: one context per HIP stream, default 1 = this
- * context has the GPU to itself).  Results never depend on it; kernel tile choices may: with other episodes in flight the idle CUs of
+ * context has the GPU to itself).  Results agree within operand rounding whatever the value — bit-identity across values is NOT
+ * promised (the N = D projections move to a kernel with another MFMA shape that folds bias and residual into the accumulator's
+ * initial value; observed bit-identical on gfx950, not guaranteed): compare or resume runs at ONE value (ttl_amd.eval's resume tag
+ * carries --streams, bench.py prints streams_per_gpu).  Kernel tile choices do depend on it: with other episodes in flight the idle CUs of
  * a partial round run their kernels, so a launch is chosen by its CU-time instead of its makespan (csrc/gemm_huge.hip: the N = D
  * projections on 256 x 256 tiles, +2.5 % images/s at three episodes in flight, slower alone).  Takes effect for the launches (and
  * graph captures) that follow. */

@@ -7,6 +7,7 @@ from ttl_amd import synth
 from ttl_amd.config import get_config
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_WEIGHTS = {}
 
 
 def load_case(name):
@@ -16,8 +17,15 @@ def load_case(name):
     if "lora_targets" in g.files:          # fixtures with adapters beyond the reference's q_proj / v_proj
         cfg = cfg.replace(lora_targets=tuple(str(t) for t in g["lora_targets"]))
     variant = str(g["weights_variant"]) if "weights_variant" in g.files else None      # "outliers": CLIP-like activation statistics
-    W = synth.vision_weights(cfg, int(g["weight_seed"]), variant=variant)
-    assert synth.checksum(W) == str(g["weights_sha256"]), "synthetic weights drifted from the fixture"
+    wkey = (cfg.name, int(g["weight_seed"]), variant)
+    if wkey not in _WEIGHTS:       # (fixtures of one model share the frozen weights: generate and checksum them once per process)
+        W = synth.vision_weights(cfg, int(g["weight_seed"]), variant=variant)
+        assert synth.checksum(W) == str(g["weights_sha256"]), "synthetic weights drifted from the fixture"
+        if len(_WEIGHTS) >= 2:     # keep at most TWO models (ViT-L/14 is 1.2 GB of fp32)
+            _WEIGHTS.pop(next(iter(_WEIGHTS)))
+        _WEIGHTS[wkey] = (W, str(g["weights_sha256"]))
+    W, sha = _WEIGHTS[wkey]
+    assert sha == str(g["weights_sha256"]), "fixtures of one (arch, seed, variant) disagree on the weights"
     x = synth.views(cfg, int(g["n_views"]), int(g["view_seed"]))
     assert synth.checksum([x]) == str(g["x_sha256"]), "synthetic views drifted from the fixture"
     lora0 = synth.lora_init(cfg, 0)

@@ -16,7 +16,7 @@ def test_library_is_built_in_tree():
         _lib.load("fp8")
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16", "strict"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "strict", "experiments"])
 def test_exports_match_header(precision):
     lib = _lib.load(precision)
     declared = _lib.header_symbols()
@@ -128,9 +128,9 @@ def test_no_load_lands_in_the_result_registers_of_an_mfma_in_flight():
         assert re.search(rf"{build}\s+gemm_big.hip\s+\d{{4}} MFMA instructions", r.stdout), r.stdout[-1500:]    # the scan really saw the kernels
 
 
-def test_the_three_builds_export_the_same_abi():
-    """libttl_hip.so, libttl_hip_fp16.so and the test-only libttl_hip_strict.so: every symbol include/ttl_hip.h declares, and
-    each says which operand type it was built for."""
+def test_the_builds_export_the_same_abi():
+    """libttl_hip_fp16.so (the surface's default), libttl_hip.so, and the test-only libttl_hip_strict.so / libttl_hip_fp16_exp.so:
+    every symbol include/ttl_hip.h declares, and each says which operand type it was built for."""
     for prec, dt in _lib.OPERAND_DTYPE.items():
         lib = _lib.load(prec)
         assert lib.ttl_operand_dtype().decode() == dt
@@ -150,3 +150,75 @@ def test_degenerate_configs_are_refused_not_crashed():
     assert lib.ttl_ctx_create(C.byref(cfg), C.byref(h)) != 0 and not h.value
     cfg = _lib.ttl_config(8, 16, 768, 12, 3072, 12, 512, 16, 32.0, 9, 11, 1e-5, 64, 200, 0, 0, 0, 0)       # image smaller than a patch
     assert lib.ttl_ctx_create(C.byref(cfg), C.byref(h)) != 0 and not h.value
+
+
+def test_the_surface_defaults_to_the_fp16_build():
+    """No precision named -> the fp16-operand library (the reference's autocast dtype, inside the 1e-3 logit tolerance); bf16 and
+    strict are opt-in; no default of the package names bf16 any more."""
+    import inspect
+    import re
+    import subprocess
+    import sys
+    from ttl_amd import custom_clip, driver, engine, views
+    assert _lib.DEFAULT_PRECISION == os.environ.get("TTL_PRECISION", "fp16")
+    if not os.environ.get("TTL_PRECISION"):
+        assert _lib.load() is _lib.load("fp16") and _lib.load().ttl_operand_dtype() == b"fp16"
+    for fn in (custom_clip.ClipTestTimeTuning.__init__, custom_clip.build_text_mode_engine, engine.TTLEngine.__init__,
+               engine.TextTowerEngine.__init__, driver.EpisodePipeline.__init__, views.make_views, views.GpuAugMixAugmenter.__init__,
+               _lib.load):
+        assert inspect.signature(fn).parameters["precision"].default is None, fn
+    pkg = os.path.dirname(_lib.__file__)
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert not re.search(r'precision(: str)? *= *"bf16"|default="bf16"', open(os.path.join(pkg, f)).read()), f
+    # the process-wide override, and a bad value is refused at import
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(pkg), os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-c", "from ttl_amd import _lib; print(_lib.DEFAULT_PRECISION, _lib.load().ttl_operand_dtype().decode())"],
+                       env=dict(env, TTL_PRECISION="bf16"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["bf16", "bf16"], r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", "from ttl_amd import _lib"], env=dict(env, TTL_PRECISION="fp8"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "TTL_PRECISION" in r.stderr
+
+
+def test_product_builds_read_five_environment_variables_and_say_which():
+    """The kernel path of a product build is frozen: the only TTL_* strings in the binaries are the five run-time switches
+    ttl_runtime_switches() lists (csrc/common.hpp TtlSwitch); the closed A/B knobs exist in the -DTTL_EXPERIMENTS build only."""
+    import re
+    import subprocess
+    want = {"TTL_GEMM_HUGE": 2, "TTL_GEMM_HUGE_NARROW": -1, "TTL_GEMM_HUGE_MIN_FILL": 85, "TTL_BWD_COMPACT": 1, "TTL_CONCURRENCY": 0}
+
+    def ttl_strings(path):
+        out = subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout
+        return sorted(set(l for l in out.splitlines() if re.fullmatch(r"TTL_[A-Z0-9_]+", l)))
+    for prec in ("fp16", "bf16", "strict"):
+        got = ttl_strings(_lib.LIB_PATHS[prec])
+        assert got == sorted(want) and len(got) <= 6, (prec, got)
+        sw = _lib.runtime_switches(prec)
+        assert {k: v[1] for k, v in sw.items()} == want, sw
+        assert all(v[0] == int(os.environ.get(k, v[1])) for k, v in sw.items())
+        assert b"EXPERIMENTS" not in _lib.load(prec).ttl_version()
+    exp = ttl_strings(_lib.LIB_PATHS["experiments"])
+    assert set(want) < set(exp) and {"TTL_QKV_HEAD_MAJOR", "TTL_POOLED_LAST_LAYER", "TTL_GEMM_HUGE_DGRAD", "TTL_ATTN_VARIANT"} <= set(exp), exp
+    assert b"EXPERIMENTS" in _lib.load("experiments").ttl_version()
+
+
+def test_workspace_bytes_is_the_allocation_walk():
+    """ttl_workspace_bytes walks ttl_ctx_create's own allocation list (nothing allocated, no GPU needed): it includes the
+    packed-backward buffers of top-k selections (round-5 advisor: the old closed formula had not followed them), grows with every
+    capacity, and follows TTL_BWD_COMPACT like the context does.  tests/test_gpu_path.py compares it with a live context."""
+    import subprocess
+    import sys
+    lib = _lib.load()
+    mk = lambda **o: _lib.ttl_config(*[o.get(k, d) for k, d in (("image_size", 224), ("patch_size", 16), ("width", 768), ("heads", 12),
+                                     ("mlp", 3072), ("layers", 12), ("embed", 512), ("rank", 16), ("lora_alpha", 32.0), ("layer_lo", 9),
+                                     ("layer_hi", 11), ("ln_eps", 1e-5), ("max_views", 64), ("max_classes", 1000))])
+    base = lib.ttl_workspace_bytes(C.byref(mk()))
+    assert 1.5e9 < base < 4e9
+    assert lib.ttl_workspace_bytes(C.byref(mk(max_views=128))) > 1.6 * base - 4e8
+    assert lib.ttl_workspace_bytes(C.byref(mk(rank=32))) > base
+    assert lib.ttl_workspace_bytes(C.byref(mk(max_classes=2000))) > base
+    code = ("import ctypes as C; from ttl_amd import _lib; "
+            "c = _lib.ttl_config(224, 16, 768, 12, 3072, 12, 512, 16, 32.0, 9, 11, 1e-5, 64, 1000); print(_lib.load().ttl_workspace_bytes(C.byref(c)))")
+    pkg = os.path.dirname(os.path.dirname(_lib.__file__))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TTL_BWD_COMPACT="0", PYTHONPATH=pkg), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and int(r.stdout) < base - 1e8, (r.stdout, r.stderr, base)      # the SelBuf set is ~30 % of the saved activations

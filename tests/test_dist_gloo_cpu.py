@@ -226,7 +226,7 @@ def _run_bench_stub(extra, env=None, n=8):
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--stub-pipeline", "--steps", "12", "--warmup", "2",
                         "--repeats", "3"] + extra, env=e, capture_output=True, text=True, timeout=600)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-2000:]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-30000:]
 
 
 def test_bench_control_flow_of_an_eight_rank_run():
@@ -246,6 +246,32 @@ def test_bench_control_flow_of_an_eight_rank_run():
     assert j["accuracy_accumulator"]["images"] == 8 * 12
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert k in j, k
+
+
+def test_bench_refuses_ranks_with_different_libraries_and_a_wrong_rank_count():
+    """The first multi-GPU run must be boring (round-5 review item 7): the N > 1 line repeats the library's sha256 per rank and a run in
+    which one rank loaded another file ends non-zero before anything is timed; so does a launch whose rank count is not --gpus."""
+    import subprocess
+    import sys
+    rc, j, err = _run_bench_stub([])
+    assert rc == 0 and j["protocol"]["lib_sha256_15_per_rank"] == ["0" * 15] * 8, (rc, err)
+    rc, j, err = _run_bench_stub([], {"TTL_BENCH_STUB_LIBSHA": "3:00000000deadbeef"})
+    assert rc != 0 and j is None and "different fp16 libraries" in err, (rc, err)
+    # launched by hand with 2 ranks while --gpus says 3: every rank refuses (WORLD_SIZE check; the ranks_seen all-reduce is the
+    # second line of defence behind it)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "3", "--stub-pipeline", "--steps", "4",
+                        "--warmup", "1"], env=dict(e, TTL_BENCH_STUB_MS="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "--gpus 3 but WORLD_SIZE=2" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def test_bench_flags_a_slow_rank_and_strict_balance_exits_3():

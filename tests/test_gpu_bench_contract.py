@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_json_line_has_the_contract_keys():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--sustain-seconds", "4"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -66,6 +66,38 @@ def test_bench_json_line_has_the_contract_keys():
     assert 10 <= d["repeats"] <= 25 and d["value_min"] <= d["value"] <= d["value_max"] and d["value_iqr"] >= 0
     assert 0 < d["host_enqueue_ms_per_image"] < d["ms_per_step"] * 1.05
     assert isinstance(d["config"]["hip_graph"], bool) and d["config"]["lora_targets"] == ["q_proj", "v_proj"]
+    # conformance is decided over every deciding fixture (named in headline_rule), the others are listed with their verdicts
+    par = d["parity"]
+    assert par["conforms_on_every_deciding_fixture"] is True and par["fixtures_deciding"][0] == "b16_n64_k200_ent0" and len(par["fixtures_deciding"]) >= 6
+    assert all(par["fixtures"][fx]["selection_mask_and_logits_within_tolerance"] for fx in par["fixtures_deciding"])
+    assert all(fx in d["headline_rule"] for fx in par["fixtures_deciding"]) and "b16_n64_k200_qkvo" in par["fixtures"]
+    assert b16["parity"]["conforms_on_every_deciding_fixture"] is False
+    assert st["conforms_on_every_deciding_fixture"] is True and st["fixtures_outside_tolerance"] == []
+    # the frozen kernel path: the five run-time switches, all at their defaults, are in the line
+    ke = d["protocol"]["kernel_env"]
+    assert set(ke) == {"TTL_GEMM_HUGE", "TTL_GEMM_HUGE_NARROW", "TTL_GEMM_HUGE_MIN_FILL", "TTL_BWD_COMPACT", "TTL_CONCURRENCY"}
+    assert d["protocol"]["kernel_env_all_default"] is True and all(v["value"] == v["default"] for v in ke.values())
+    # a continuous run of the headline leg (no fence between images) beside the 1.5-s timed blocks
+    su = d["sustained"]
+    assert su["dtype"] == "fp16" and 3.5 < su["seconds"] < 15 and su["images"] >= 6 * 50 and su["value"] > 50
+    assert 0.85 < su["ratio_to_value"] < 1.15 and su["value_last_20s"] > 50
+    ts = d["torch_stack_same_gpu"]
+    assert ts["static"] is True and ts["value"] > 10 and ts["source"].startswith("profiles/") and ts["ratio"] > 2
+
+
+def test_bench_refuses_a_kernel_switch_off_its_default_unless_asked():
+    """A stray TTL_GEMM_HUGE=0 (or any other run-time switch of the library off its default) in the environment would change the
+    measured kernel path silently: refused, like a swapped library; --variant-env allows it and the line records it."""
+    env = dict(os.environ, TTL_GEMM_HUGE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "--variant-env" in (r.stderr + r.stdout) and "TTL_GEMM_HUGE=0" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    # a closed experiment's name is not a switch of the product build: it changes nothing and is not refused
+    d = _run(["--steps", "6", "--repeats", "2", "--precision", "fp16", "--sustain-seconds", "0"], env=dict(os.environ, TTL_ATTN_VARIANT="1", TTL_GEMM_BIG="0"))
+    assert d["protocol"]["kernel_env_all_default"] is True
+    d = _run(["--steps", "6", "--repeats", "2", "--precision", "fp16", "--sustain-seconds", "0", "--variant-env"], env=env)
+    assert d["protocol"]["kernel_env"]["TTL_GEMM_HUGE"] == {"value": 0, "default": 2} and d["protocol"]["kernel_env_all_default"] is False
 
 
 def test_bench_refuses_a_swapped_library_unless_asked():
@@ -113,7 +145,7 @@ print("RCCL_OK")
 
 def _run(extra, env=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--warmup", "2", "--no-cpu-baseline", "--no-parity",
-                        "--precision", "bf16", "--streams", "2"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--precision", "bf16", "--streams", "2", "--sustain-seconds", "0"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

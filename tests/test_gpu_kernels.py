@@ -358,11 +358,17 @@ def test_gemm_wide_fused_forms(lib, prec):
         G.check(lib, prec, *shp)
     G.check(lib, prec, 12608, 2304, 768, 197, lda_pad=64)            # A as the first K columns of a wider buffer
     G.check(lib, prec, 12608, 2304, 768, 197, with_bias=False)       # null bias
-    for mode in ("0", "1"):      # (mode 1 with the round-fill rule off: every shape on gemm_huge.hip)
-        out = subprocess.run([sys.executable, G.__file__, prec], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0", TTL_GEMM_HUGE_DGRAD="1"),
+    n_dgrad = sum(1 for shp in G.SHAPES if shp[3] == -1)
+    # (mode 1 with the round-fill rule off: every q/k/v and fc1 shape on gemm_huge.hip; the MLP-dgrad form there is a closed experiment
+    # that only the experiments build — the fp16 library with -DTTL_EXPERIMENTS — switches on: third child, fp16 round only)
+    runs = [("0", prec, {}, 0), ("1", prec, {}, len(G.SHAPES) - n_dgrad)]
+    if prec == "fp16":
+        runs.append(("1", "experiments", {"TTL_GEMM_HUGE_DGRAD": "1"}, len(G.SHAPES)))
+    for mode, build, extra, n_huge in runs:
+        out = subprocess.run([sys.executable, G.__file__, build], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0", **extra),
                              capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0 and f"ok {prec} mode {mode}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-        assert f"on gemm_huge: {len(G.SHAPES) if mode == '1' else 0}" in out.stdout, out.stdout[-500:]
+        assert out.returncode == 0 and f"ok {build} mode {mode}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        assert f"on gemm_huge: {n_huge}" in out.stdout, out.stdout[-500:]
 
 
 def test_gradscaler_known_answers(lib, prec):

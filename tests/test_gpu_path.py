@@ -163,6 +163,21 @@ def test_half_precision_checkpoints_and_the_logit_head_entry():
         eng._check(eng.lib.ttl_load_weight_typed(eng._h, b"visual_projection.weight", None, 4, 7))
 
 
+@pytest.mark.parametrize("arch,n,k,targets", [("tiny", 8, 10, None), ("ViT-B/16", 64, 200, None), ("ViT-B/16", 16, 1000, ("q_proj", "k_proj", "v_proj", "out_proj"))])
+def test_workspace_bytes_equals_what_a_context_allocates(arch, n, k, targets):
+    """ttl_workspace_bytes(cfg) == ttl_ctx_allocated_bytes(ctx) for an owning context (round-5 advisor: the figure had not followed
+    the packed-backward buffers); a sharing context holds less; a PLPD stage adds the documented lazily allocated buffers."""
+    from ttl_amd.config import get_config
+    from ttl_amd.engine import TTLEngine
+    cfg = get_config(arch)
+    if targets:
+        cfg = cfg.replace(lora_targets=targets)
+    for prec in ("fp16", "strict"):
+        eng = TTLEngine(cfg, n, k, "cuda:0", precision=prec)
+        assert eng.allocated_bytes() == eng.workspace_bytes() > 0, (prec, eng.allocated_bytes(), eng.workspace_bytes())
+        eng.close()
+
+
 def test_errors_are_loud():
     from ttl_amd import _lib
     from ttl_amd.config import get_config
@@ -516,7 +531,7 @@ def test_three_episodes_in_flight_are_bitwise_repeatable():
     torch.cuda.synchronize()
     eng.close()
     pipe = EpisodePipeline(cfg, W, names, lora0, torch.from_numpy(tf), float(np.exp(W["logit_scale"])), "cuda:0",
-                           n_streams=3, max_views=x.shape[0])
+                           n_streams=3, max_views=x.shape[0], precision=eng.precision)
     order = [0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1]
     outs = [pipe.submit((x0, x1)[j], n_updates=1) for j in order]
     pipe.synchronize()
@@ -551,7 +566,7 @@ def test_ragged_calls_inside_a_larger_context():
     from ttl_amd import _lib
     g, cfg, W, x, lora0, tf = load_case("tiny_deyo")
     exact, flat, names = make_engine(cfg, W, lora0, tf, 5)
-    big = TTLEngine(cfg, max_views=64, max_classes=1000, device="cuda:0")
+    big = TTLEngine(cfg, max_views=64, max_classes=1000, device="cuda:0", precision=exact.precision)
     big.load_weights(W)
     big.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
     flat2 = flat.clone()
@@ -652,7 +667,7 @@ def test_k_and_out_proj_adapters_vs_oracle(arch, rank, targets):
         eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["experiments"])       # TTL_QKV_HEAD_MAJOR is a closed experiment: only the -DTTL_EXPERIMENTS build (fp16 operands) reads it
 @pytest.mark.parametrize("targets", [None, ("q_proj", "k_proj", "v_proj", "out_proj")])
 def test_head_major_qkv_changes_addresses_only(monkeypatch, precision, targets):
     """The big-M QKV GEMM writes q/k/v head-major ([view][q|k|v][head][T][64]: contiguous tiles for the attention kernels, HF
@@ -705,7 +720,7 @@ def test_shared_weight_images_give_the_same_bits():
     loraB = {k: ((rng.standard_normal(v.shape) * 0.02).astype(np.float32) if "lora_B" in k else v) for k, v in lora0.items()}
     own, flat_o, names = make_engine(cfg, W, lora0, tf, x.shape[0])
     priv, flat_p, _ = make_engine(cfg, W, loraB, tf, x.shape[0])
-    sh = TTLEngine(cfg, max_views=x.shape[0], max_classes=tf.shape[0], device="cuda:0", share_from=own)
+    sh = TTLEngine(cfg, max_views=x.shape[0], max_classes=tf.shape[0], device="cuda:0", precision=own.precision, share_from=own)
     with pytest.raises(_lib.TtlError, match="shares its parent"):
         sh.load_weights({"visual_projection.weight": W["visual_projection.weight"]})
     sh.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
@@ -943,6 +958,40 @@ def test_backward_on_the_selected_views_only(monkeypatch, precision, name, objec
         assert (d > 1e-6).mean() < 2e-3
     else:       # every later step starts from the flipped elements of the one before: count those a tenth of a step (lr = 5e-3) apart
         bound(f"packed_backward/{name}/{objective}/{n_updates}/{precision}/frac_beyond_0.1lr", (d > 5e-4).mean(), 0.1)
+    assert max_rel(res["1"]["l1"], res["0"]["l1"]) < (1e-4 if precision == "strict" else 5e-3)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "strict"])
+def test_packed_backward_after_a_dense_last_layer(monkeypatch, precision):
+    """1 100 views (>= 1 024: the forward runs its last layer DENSELY, LN2 statistics at pitch T) with a top-rho selection of 110
+    (< 1 024): the packed backward must read the statistics in the layout the SAVING forward left (ttl_ctx::saved_pooled), not the
+    one the packed view count would imply (round-5 advisor).  Checked against the full backward of the same context type."""
+    from ttl_amd import synth
+    from ttl_amd.config import get_config
+    cfg = get_config("tiny")
+    W = synth.vision_weights(cfg, 0)
+    lora0 = synth.lora_init(cfg, 1)
+    rng = np.random.default_rng(3)
+    for k in lora0:                            # B != 0: every gradient tensor is non-zero
+        if "lora_B" in k:
+            lora0[k] = (rng.standard_normal(lora0[k].shape) * 0.02).astype(np.float32)
+    tf = synth.text_features(10, cfg.embed, 2)
+    n = 1100
+    xd = torch.from_numpy(synth.views(cfg, n, 7)).cuda()
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("TTL_BWD_COMPACT", on)            # read when a context is created
+        eng, flat, names = make_engine(cfg, W, lora0, tf, n, precision=precision)
+        snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+        l1 = eng.episode(xd, snap, m, v, mode=1, rho=0.1, n_updates=1).clone()
+        torch.cuda.synchronize()
+        idx, _ = eng.last_selection(n)
+        res[on] = dict(l1=l1.cpu().numpy(), grads=eng.grads.clone().cpu().numpy(), idx=np.asarray(idx))
+        eng.close()
+    assert np.array_equal(res["1"]["idx"], res["0"]["idx"]) and len(res["1"]["idx"]) == 110
+    for k, a in split(torch.from_numpy(res["1"]["grads"]), lora0, names).items():
+        b = split(torch.from_numpy(res["0"]["grads"]), lora0, names)[k]
+        assert np.abs(b).max() > 0 and max_rel(a, b) < 2e-5, (k, max_rel(a, b))
     assert max_rel(res["1"]["l1"], res["0"]["l1"]) < (1e-4 if precision == "strict" else 5e-3)
 
 

@@ -88,6 +88,37 @@ def test_plpd_keep_vs_the_reference_formula():
     eng.close()
 
 
+def test_plpd_keep_survives_nan_and_all_minus_inf_rows():
+    """A candidate row of logits that is all -inf, or holds NaNs (a NaN entropy ranks first in the top-k selection, so such a row DOES
+    become a candidate): torch.argmax answers index 0 / the first NaN and the reference's comparison `plpd > threshold` is False for
+    the NaN difference (deyo.py:137-146) — the view is dropped, nothing faults, the other rows are unaffected."""
+    from ttl_amd.config import get_config
+    from ttl_amd.engine import TTLEngine
+    eng = TTLEngine(get_config("tiny"), 8, 10, "cuda:0", precision="fp16")
+    g = torch.Generator().manual_seed(5)
+    for N, K in ((8, 10), (16, 1000), (6, 300)):
+        z = (torch.randn(N, K, generator=g) * 3).cuda()
+        z[0] = float("-inf")
+        z[2, K // 2] = float("nan")
+        z[3] = float("nan")
+        z[4, 1] = float("inf")
+        idx = torch.arange(N, dtype=torch.int64).cuda()
+        zp = z.clone().nan_to_num(0.0, 0.0, 0.0) + torch.randn(N, K, generator=g).cuda() * 2
+        n = torch.tensor([N], dtype=torch.int32).cuda()
+        keep, val = eng.plpd_keep(z, zp, idx, n, N, 0.2)
+        torch.cuda.synchronize()
+        prob, prob_p = z.softmax(1), zp.softmax(1)
+        cls1 = prob.argmax(dim=1)                            # (index 0 for the -inf row — softmax of it is NaN — and the first NaN otherwise)
+        plpd = (torch.gather(prob, 1, cls1.reshape(-1, 1)) - torch.gather(prob_p, 1, cls1.reshape(-1, 1))).reshape(-1)
+        bad = torch.isnan(plpd)
+        assert bad[[0, 2, 3, 4]].all() and not bad[[1, 5]].any()
+        assert torch.isnan(val[bad]).all() and not keep[bad].any()              # dropped, like `nan > threshold`
+        assert (val[~bad] - plpd[~bad]).abs().max().item() < 2e-6
+        clear = ~bad & ((plpd - 0.2).abs() > 1e-5)
+        assert torch.equal(keep[clear], (plpd > 0.2).to(torch.uint8)[clear])
+    eng.close()
+
+
 def survivors(eng, n_views, n_candidates, n_expected, g):
     """The second-stage list filter_ids_1[filter_ids_2] (deyo.py:146-151) as the context holds it after a PLPD update: "idx" is the
     FIRST-stage list (the reference's order), "keep" the mask over views, "n_selected" the number of survivors."""

@@ -48,7 +48,8 @@ np.savez(sys.argv[1], **out)
 
 def run(tmp_path, flag):
     out = tmp_path / f"pooled{flag}.npz"
-    env = dict(os.environ, TTL_POOLED_LAST_LAYER=str(flag))
+    # TTL_POOLED_LAST_LAYER is a closed experiment: the -DTTL_EXPERIMENTS build of the fp16 library is the one that reads it
+    env = dict(os.environ, TTL_POOLED_LAST_LAYER=str(flag), TTL_PRECISION="experiments")
     r = subprocess.run([sys.executable, "-c", f"ROOT={ROOT!r}\n" + SCRIPT, str(out)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return np.load(out)

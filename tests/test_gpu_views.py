@@ -77,7 +77,7 @@ def test_gpu_augmenter_feeds_the_episode():
     W = synth.vision_weights(cfg, 0)
     lora0 = synth.lora_init(cfg, 1)
     tf = synth.text_features(10, cfg.embed, 2)
-    eng = TTLEngine(cfg, 8, 10, "cuda:0")
+    eng = TTLEngine(cfg, 8, 10, "cuda:0", precision="bf16")       # (checked against the bf16-emulating oracle below)
     eng.load_weights(W)
     eng.set_text_features(torch.from_numpy(tf), float(np.exp(W["logit_scale"])))
     names = O.trainable_names(cfg)

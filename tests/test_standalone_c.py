@@ -59,7 +59,7 @@ def test_standalone_c_host_matches_python_engine(tmp_path):
     bundle = write_bundle(tmp_path, cfg, W, tf, scale, flat, x)
     exe = build(tmp_path)
     out = tmp_path / "out.bin"
-    r = subprocess.run([exe, _lib.LIB_PATHS["bf16"], str(bundle), str(out)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, _lib.LIB_PATHS[_lib.DEFAULT_PRECISION], str(bundle), str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = np.fromfile(out, dtype=np.float32)
     z0, z1 = got[:N * K].reshape(N, K), got[N * K:].reshape(1, K)

@@ -138,6 +138,8 @@ struct ttl_ctx {
     std::vector<SelBuf> selb;                  // one per saved layer (layer_lo .. L-1)
     float *sel_mean = nullptr, *sel_rstd = nullptr, *sel_y = nullptr, *sel_f = nullptr, *sel_h = nullptr, *sel_dz = nullptr;
     bool saved = false; int saved_n = 0; int stream_views = 0;
+    bool dry = false;               // sizing walk of ctx_create_impl (ttl_workspace_bytes): no HIP call is made
+    bool saved_pooled = false;      // the saved forward ran its last layer on the pooled rows only (LN2 statistics of that layer: [n], not [n*T])
     // profiling
     bool prof = false; double prof_ms[TTL_NCLASS] = {}; long long prof_n[TTL_NCLASS] = {}; double gemm_flops = 0, gemm_flops_all = 0, gemm_flops_all_last = 0, gemm_bytes = 0, gemm_bytes_last = 0;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -150,6 +152,7 @@ int dalloc(ttl_ctx* c, Tp** p, size_t count, bool zero = false) {
     void* q = nullptr;
     size_t bytes = count * sizeof(Tp);
     if (bytes == 0) bytes = 16;
+    if (c->dry) { c->bytes += bytes; *p = nullptr; return 0; }     // ttl_workspace_bytes: the same walk, nothing allocated
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess) return fail(TTL_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     if (zero) {
@@ -275,22 +278,51 @@ enum { HW_CLS = 1, HW_PATCH = 2, HW_POS = 4, HW_PREG = 8, HW_PREB = 16, HW_POSTG
 extern "C" {
 
 const char* ttl_last_error(void) { return g_err; }
-const char* ttl_version(void) { return "ttl_hip 0.2 (gfx950, " TTL_OPERAND_NAME " operands)"; }
+#ifdef TTL_EXPERIMENTS
+const char* ttl_version(void) { return "ttl_hip 0.3 (gfx950, " TTL_OPERAND_NAME " operands, EXPERIMENTS build: closed A/B switches are read from the environment)"; }
+#else
+const char* ttl_version(void) { return "ttl_hip 0.3 (gfx950, " TTL_OPERAND_NAME " operands)"; }
+#endif
+
+// ---- the run-time switches of the product build (csrc/common.hpp TtlSwitch): name, default, what it selects
+namespace {
+struct SwitchInfo { const char* name; int dflt; const char* what; };
+const SwitchInfo kSwitches[SW_COUNT] = {
+    {"TTL_GEMM_HUGE", 2, "256x256 four-wave GEMM tiles: 0 off, 1 q/k/v + fc1, 2 q/k/v only, 3 fc1 only (read once per process)"},
+    {"TTL_GEMM_HUGE_NARROW", -1, "N = D launches on the 256x256 tiles: -1 when the context runs beside other episodes, 0 never, 1 always (once per process)"},
+    {"TTL_GEMM_HUGE_MIN_FILL", 85, "percent of one round of CUs a launch must fill with 256x256 tiles (once per process)"},
+    {"TTL_BWD_COMPACT", 1, "top-k selections: backward on the selected views' packed activations (read when a context is created)"},
+    {"TTL_CONCURRENCY", 0, "default of ttl_ctx_set_concurrency for new contexts; 0 = 1 (read when a context is created)"},
+};
+}  // namespace
+
+extern "C++" int ttl_switch(TtlSwitch id) { return ttl_env_int(kSwitches[id].name, kSwitches[id].dflt); }
+
+const char* ttl_runtime_switches(void) {
+    static thread_local char buf[1024];
+    size_t off = 0;
+    for (int i = 0; i < SW_COUNT && off < sizeof buf; ++i)
+        off += (size_t)snprintf(buf + off, sizeof buf - off, "%s=%d default=%d # %s\n", kSwitches[i].name, ttl_switch((TtlSwitch)i),
+                                kSwitches[i].dflt, kSwitches[i].what);
+    return buf;
+}
 const char* ttl_operand_dtype(void) { return TTL_OPERAND_NAME; }
 
+static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out, bool dry = false);
+static void ctx_release(ttl_ctx* c);
+
+// The footprint of an OWNING context, exactly: the allocation walk of ttl_ctx_create with nothing allocated (no HIP call: works without
+// a GPU).  ttl_ctx_allocated_bytes() of a context created with the same configuration (and the same TTL_BWD_COMPACT) returns this
+// figure until a PLPD stage adds its lazily allocated buffers (documented in include/ttl_hip.h).
 size_t ttl_workspace_bytes(const ttl_config* k) {
-    if (check_config(k)) return 0;
-    ttl_ctx t; set_geometry(&t, k);
-    size_t D = t.D, F = t.F, M = t.Mmax, L = t.L, nT = t.nS, N = k->max_views;   // (saved layers: layer_lo..L-1)
-    const size_t ldo = D + (t.has_o ? 64 : 0);
-    const size_t ob = sizeof(op_t);    // bytes per operand element (2; 4 in the strict build)
-    size_t w = L * (3 * D * t.ldw + D * ldo + 2 * D * F) * ob + nT * (D * t.ldwt + D * ldo + 2 * D * F) * ob + D * t.Kp * ob + 2 * t.E * D * 4 +
-               (t.text ? (size_t)k->vocab_size * D * 4 : 0);
-    size_t act = (size_t)N * t.G2 * t.Kp * ob + M * D * 4 * (1 + 3 * nT) + nT * (M * t.ldx + (M + t.T) * 3 * D + M * ldo + M * F) * ob +
-                 (M * D + (M + t.T) * 3 * D + M * D + M * D + M * F) * ob + M * D * 4 * 3 + (M * t.ldh + M * F + M * (D + 64) + M * t.ldwt) * ob +
-                 (size_t)lora_wgrad_chunks((int)M) * 2 * t.ntg * t.r * D * 4;
-    return w + act;
+    ttl_ctx* c = nullptr;
+    if (ctx_create_impl(k, nullptr, &c, true) || !c) return 0;
+    const size_t b = c->bytes;
+    ctx_release(c);
+    return b;
 }
+
+size_t ttl_ctx_allocated_bytes(const ttl_ctx* c) { return c ? c->bytes : 0; }
 
 // The weight-side configuration two contexts must agree on to share frozen images (capacities may differ)
 static bool same_model(const ttl_config& a, const ttl_config& b) {
@@ -300,7 +332,7 @@ static bool same_model(const ttl_config& a, const ttl_config& b) {
            (a.lora_targets ? a.lora_targets : (TTL_LORA_Q | TTL_LORA_V)) == (b.lora_targets ? b.lora_targets : (TTL_LORA_Q | TTL_LORA_V));
 }
 
-static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) {
+static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out, bool dry) {
     if (!out) return fail(TTL_EINVAL, "null out");
     *out = nullptr;
     int rc = check_config(k);
@@ -310,26 +342,28 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
         if (!same_model(*k, parent->c)) return fail(TTL_EINVAL, "a shared context needs the parent's model configuration (capacities may differ)");
         if ((rc = ttl_weights_ready(parent))) return rc;
     }
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0) return fail(e != hipSuccess ? (int)e : TTL_ESTATE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (!dry) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) return fail(e != hipSuccess ? (int)e : TTL_ESTATE, "no HIP device available (%s)", hipGetErrorString(e));
+    }
     ttl_ctx* c = new ttl_ctx();
+    c->dry = dry;
     set_geometry(c, k);
     c->parent = parent;
     if (parent) parent->refs.fetch_add(1);
     const size_t D = c->D, F = c->F, M = c->Mmax, E = c->E, N = k->max_views, T = c->T, H = c->H, r = c->r;
     // frozen tensor: the parent's image (never written after loading) or an allocation of this context's own
 #define WSHARE(dst, src, count, zero) do { if (parent) (dst) = (src); else ALLOC(dst, count, zero); } while (0)
-    struct Guard { ttl_ctx* c; bool ok = false; ~Guard() { if (!ok) ttl_ctx_destroy(c); } } guard{c};
+    struct Guard { ttl_ctx* c; bool ok = false; ~Guard() { if (!ok) { if (c->dry) ctx_release(c); else ttl_ctx_destroy(c); } } } guard{c};
     {   // head-major q/k/v: needs row / T by multiply-high for every row a big-M launch can store
-        const char* v = getenv("TTL_QKV_HEAD_MAJOR");
         c->hm_magic = qkv_hm_magic((int)T, (int)M + 320);
-        c->use_hm = (v ? atoi(v) != 0 : 1) && c->hm_magic != 0;
+        c->use_hm = TTL_EXPERIMENT("TTL_QKV_HEAD_MAJOR", 1) != 0 && c->hm_magic != 0;
     }
     {   // TTL_CONCURRENCY: the default of ttl_ctx_set_concurrency for every context of the process (profiling a single stream with the
         // kernels of the three-stream run)
-        const char* v = getenv("TTL_CONCURRENCY");
-        if (v && atoi(v) >= 1) c->concurrency = atoi(v);
+        const int v = ttl_switch(SW_CONCURRENCY);
+        if (v >= 1) c->concurrency = v;
     }
     c->layers.resize(c->L);
     for (int i = 0; i < c->L; ++i) {
@@ -398,9 +432,8 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
     ALLOC(c->dcls16, N * D, false); ALLOC(c->dgc, N * F, false); ALLOC(c->dhmc16, N * c->ldh, true); ALLOC(c->doc, N * D, false);
     ALLOC(c->att_g, N * (D + 64), true);
     {
-        const char* v = getenv("TTL_BWD_COMPACT");
         const int cap = (int)N / 4;          // top-k selections keep 10 % of the views (ttl.py:376); a quarter of them fit
-        if ((v ? atoi(v) != 0 : 1) && !c->text && cap >= 1 && c->nS > 0) {
+        if (ttl_switch(SW_BWD_COMPACT) != 0 && !c->text && cap >= 1 && c->nS > 0) {
             c->sel_cap = cap;
             c->sel_rows = round_up(cap * (int)T, 1280);
             const size_t Ms = (size_t)c->sel_rows;
@@ -430,7 +463,7 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out) 
     {   // fp16-operand build: dynamic loss scaling from 2^10 like the reference's GradScaler(init_scale=1000) (ttl.py:222);
         // bf16 needs no loss scale (scale 1, fixed) but keeps the whole-step skip on non-finite gradients
         const float init[SC_NF] = {TTL_GRAD_SCALE, 1.0f / TTL_GRAD_SCALE, 1.f, 1.f};
-        HIP_TRY(hipMemcpy(c->sc.f, init, sizeof init, hipMemcpyHostToDevice));
+        if (!dry) HIP_TRY(hipMemcpy(c->sc.f, init, sizeof init, hipMemcpyHostToDevice));
         c->sc_dynamic = (TTL_GRAD_SCALE != 1.0f);
     }
     guard.ok = true;
@@ -747,6 +780,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     const int D = c->D, F = c->F, T = c->T, M = n * T, H = c->H;
     if (!images_fresh && (rc = lora_refresh(c, s))) return rc;
     float* h = c->h;
+    bool pooled_now = false;
     if (from_layer == 0 && c->text) {
         Prof p(c, 3, s);
         HIP_TRY(launch_text_embed(c->ids, c->tok, c->pos, c->h, M, T, D, s));   // no pre-LN in the text tower
@@ -796,8 +830,9 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             HIP_TRY(launch_lora_skinny(x1, ldx1, xoff, c->nqkv, l.acat, D, c->r, c->scaling, x1 + D, ldx1, M, s));
         }
         // TTL_POOLED_LAST_LAYER=0: run the last layer densely (A/B and the equivalence test)
-        static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
+        static const int pooled_last = TTL_EXPERIMENT("TTL_POOLED_LAST_LAYER", 1);
         if (pooled_last && i == c->L - 1 && n < 1024) {   // (row maps / compact [n, .] buffers: guarded small-M GEMM kernels only)
+            pooled_now = true;     // -> ttl_ctx::saved_pooled: the backward and the view packing read the LN2 statistics where THIS forward left them
             // ---- last layer: the head reads ONE row per sequence (image tower: CLS, HF modeling_clip.py pooled =
             // last_hidden_state[:, 0]; text tower: the end-of-text token), so beyond K and V of every token everything
             // runs on those n rows: the query projection, attention for that query, out_proj, LN2 and the MLP — in place,
@@ -919,6 +954,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     }
     c->saved = save != 0;
     c->saved_n = n;
+    if (save) c->saved_pooled = pooled_now;
     return 0;
 }
 
@@ -1010,7 +1046,6 @@ static int selected_views(const ttl_ctx* c, int n, int mode, double rho) {
 // Pack what the backward reads of views sel_idx[0 .. n_sel) (device list) into the context's SelBuf set: one launch.
 static int pack_selected_views(ttl_ctx* c, const float* dlogits, int n, const long long* sel_idx, int n_sel, hipStream_t s) {
     const size_t D = c->D, F = c->F, T = c->T, H = c->H, E = c->E, K = c->K;
-    static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
     GatherTable t = {};
     hipError_t err = hipSuccess;
     Prof p(c, 3, s);
@@ -1030,7 +1065,7 @@ static int pack_selected_views(ttl_ctx* c, const float* dlogits, int n, const lo
         add(l.lse, b.lse, H * T * 4, H * T * 4);
         add(l.u, b.u, T * F * sizeof(op_t), T * F * sizeof(op_t));
         add(l.h_mid, b.h_mid, T * D * 4, T * D * 4);
-        const size_t st2 = (top && pooled_last && n < 1024) ? 4 : T * 4;       // pooled last layer: one LN2 statistic per view
+        const size_t st2 = (top && c->saved_pooled) ? 4 : T * 4;              // pooled last layer: one LN2 statistic per view
         add(l.mu2, b.mu2, st2, st2); add(l.rs2, b.rs2, st2, st2);
         if (l.lora) add(l.x1ext, b.x1ext, T * c->ldx * sizeof(op_t), T * c->ldx * sizeof(op_t));
         if (!first) {                                                          // LN1 backward: not reached in the first trained layer
@@ -1103,8 +1138,9 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
             const op_t* u_rows = l.u; int ld_u = T * F;
             const float* hmid_rows = l.h_mid; long long hmid_pitch = (long long)T * D;
             const float *mu2 = l.mu2, *rs2 = l.rs2;
-            static const int pooled_last = [] { const char* v = getenv("TTL_POOLED_LAST_LAYER"); return v ? atoi(v) : 1; }();
-            const bool compact_stats = pooled_last && n < 1024;   // the pooled-row forward stores them as [n]
+            // the pooled-row forward stores them as [n]: decided by the forward that SAVED them (n is n_sel in a packed run: a dense
+            // forward of >= 1024 views leaves them at pitch T, and pack_selected_views copies that layout)
+            const bool compact_stats = c->saved_pooled;
             int stat_pitch = compact_stats ? 1 : T;
             if (pool) {
                 Prof p(c, 3, s);
@@ -1588,7 +1624,7 @@ int ttl_gemm_nt(const void* A, int lda, const void* B, int ldb, float* C, int ld
     GemmArgs a = {};
     a.A = (const op_t*)A; a.lda = lda; a.B = (const op_t*)B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
     // TTL_GEMM_PADDED=1: the caller's C has round_up(M,1280) rows -> the unguarded product kernels (bench tools)
-    static const int padded = [] { const char* v = getenv("TTL_GEMM_PADDED"); return v ? atoi(v) : 0; }();
+    static const int padded = TTL_EXPERIMENT("TTL_GEMM_PADDED", 0);
     a.padded = padded ? round_up(M, 1280) : 0;
     hipError_t e = launch_gemm(EPI_F32, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "gemm: %s (need K%%64==0, N%%128==0)", hipGetErrorString(e));

@@ -1056,7 +1056,7 @@ hipError_t fwd_p(const op_t* qkv, QkvLayout ld, op_t* out, int ldo, float* lse, 
     if (!cus) return hipErrorInvalidDevice;
     const int nprob = n * H;
     const int grid = nprob < cus ? nprob : cus;
-    static const int xmap = [] { const char* v = getenv("TTL_ATTN_XCD_MAP"); return v ? atoi(v) : 0; }();
+    static const int xmap = TTL_EXPERIMENT("TTL_ATTN_XCD_MAP", 0);
     hipLaunchKernelGGL((attn_fwd_p_kernel<NKT, CH>), dim3(grid), dim3(64 * NKT), SMEM, s, qkv, ld, out, ldo, lse, T, H, nprob, xmap);
     return hipGetLastError();
 }
@@ -1126,7 +1126,7 @@ hipError_t launch_attention_fwd(const op_t* qkv, QkvLayout ld_qkv, op_t* out, in
     if (nkt <= 2) return fwd_t<2>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
     if (nkt == 3) return fwd_w<3, 3>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);   // text tower: T = 77
     if (nkt <= 4) return fwd_t<4>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s, causal);
-    static const int variant = [] { const char* v = getenv("TTL_ATTN_VARIANT"); return v ? atoi(v) : 4; }();
+    static const int variant = TTL_EXPERIMENT("TTL_ATTN_VARIANT", 4);
     if (variant == 5 && !causal && n * H >= 512 && nkt == 7)      // persistent + per-tile software pipeline (round 4)
         return fwd_s<7>(qkv, ld_qkv, out, ld_out, lse, n, T, H, s);
     if (variant == 4 && !causal && n * H >= 512) {     // persistent, K/V of the next problem prefetched (big launches only)

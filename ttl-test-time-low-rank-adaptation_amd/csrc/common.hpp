@@ -2,6 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// ---- switches.  The PRODUCT libraries (libttl_hip.so, libttl_hip_fp16.so, libttl_hip_strict.so) read exactly the environment
+// variables of this table — ttl_runtime_switches() (include/ttl_hip.h) lists them with default and current value, bench.py prints them
+// under protocol.kernel_env and refuses to run with a non-default one unless --variant-env is given.  Every other TTL_* knob the
+// sources mention is a CLOSED experiment (measured neutral or slower, profiles/r0*_experiments.txt): TTL_EXPERIMENT(name, default)
+// is the constant `default` — no getenv, no string in the binary — unless the library is built with -DTTL_EXPERIMENTS
+// (libttl_hip_fp16_exp.so: TEST / tools only, never benched as the product; tools/hip_variant.sh builds its variants that way).
+enum TtlSwitch { SW_GEMM_HUGE = 0, SW_GEMM_HUGE_NARROW, SW_GEMM_HUGE_MIN_FILL, SW_BWD_COMPACT, SW_CONCURRENCY, SW_COUNT };
+int ttl_switch(TtlSwitch id);          // api.hip: the variable's value in the environment NOW, else its default
+static inline int ttl_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#ifdef TTL_EXPERIMENTS
+#define TTL_EXPERIMENT(name, dflt) ttl_env_int(name, dflt)
+#else
+#define TTL_EXPERIMENT(name, dflt) (dflt)
+#endif
 
 // ---- operand type of every MFMA product (activations, weights, attention probabilities).
 // Default build: bf16 (BASELINE.json north_star).  -DTTL_OPERAND_FP16 builds libttl_hip_fp16.so with

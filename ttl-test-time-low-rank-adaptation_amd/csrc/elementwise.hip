@@ -449,7 +449,7 @@ hipError_t launch_layernorm(const float* x, long long row_stride, const float* g
     if (rows >= 4096 && !y_f32 && y_bf16 && !rowmap && row_stride == D) {
         const int cus = device_cu_count();
         if (!cus) return hipErrorInvalidDevice;
-        static const int pblk = [] { const char* v = getenv("TTL_LN_PBLK"); const int b = v ? atoi(v) : 8; return b < 1 ? 1 : b; }();
+        static const int pblk = [] { const int b = TTL_EXPERIMENT("TTL_LN_PBLK", 8); return b < 1 ? 1 : b; }();
         if (D <= 768) hipLaunchKernelGGL(ln_fwd_persist_kernel<3>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
         else hipLaunchKernelGGL(ln_fwd_persist_kernel<4>, dim3(cus * pblk), dim3(256), 0, s, x, gamma, beta, y_bf16, ld_bf16, mean, rstd, rows, D, eps);
         return hipGetLastError();

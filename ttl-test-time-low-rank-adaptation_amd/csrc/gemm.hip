@@ -272,7 +272,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     b.xc = 0;
     int nblk = ntm * ntn;
-    static const int xcd2d = [] { const char* v = getenv("TTL_GEMM_XCD2D"); return v ? atoi(v) : 2; }();   // 0 = 1-D order; n = slice limit n*1.5 MiB (+1 % in situ)
+    static const int xcd2d = TTL_EXPERIMENT("TTL_GEMM_XCD2D", 2);   // 0 = 1-D order; n = slice limit n*1.5 MiB (+1 % in situ)
     if (xcd2d && a.M >= 1024 && a.splits == 1 && ntm >= 8) {
         // columns of the XCD grid: halve the weight slice until it sits comfortably in a 4 MiB L2
         const size_t limit = (size_t)xcd2d * 1536 * 1024;
@@ -319,7 +319,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 // flight), the guarded epilogue and a small tile (see launch_v).
 template <int EPI>
 hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
-    static const int variant = [] { const char* v = getenv("TTL_GEMM_VARIANT"); return v ? atoi(v) : 2; }();
+    static const int variant = TTL_EXPERIMENT("TTL_GEMM_VARIANT", 2);
     if (a.M < 1024) {
         // Small-M calls (1-view inference, pooled-row GEMMs of the last layer and of its backward: M = 64..257) are
         // latency chains on a handful of blocks, so the tile is SMALL to spread them over more CUs.  In situ, ms of
@@ -339,7 +339,7 @@ hipError_t launch_v(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 bool gemm_takes_big(GemmEpi epi, const GemmArgs& a) {
-    static const bool use_big = [] { const char* v = getenv("TTL_GEMM_BIG"); return v ? atoi(v) != 0 : true; }();
+    static const bool use_big = TTL_EXPERIMENT("TTL_GEMM_BIG", 1) != 0;
     return use_big && a.padded && gemm_big_applicable(epi, a) && (size_t)((a.M + 159) / 160) * 160 <= (size_t)a.padded;
 }
 

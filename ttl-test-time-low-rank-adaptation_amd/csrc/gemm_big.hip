@@ -460,11 +460,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
     }
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int MT, int STAGES, int EPI>
 hipError_t launch_big_t(const GemmArgs& a, int order, int max_blocks, hipStream_t s) {
     constexpr int BM = 32 * MT;
@@ -508,7 +503,7 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
     // MLP dgrad: its epilogue reads u (8*MT registers fetched ahead in gemm.hip).  Tried here with u fetched behind the last
     // barrier: 82 us per launch vs 83-87 us on gemm.hip's kernel (the 77 MB read stays exposed either way) at the price of spills.
     if (epi == EPI_GELU_BWD) {      // 128-row tiles with u read at the top of the tile (TTL_GEMM_BIG_DGRAD=0: gemm.hip's 160 x 128 kernel)
-        static const bool on = [] { const char* v = getenv("TTL_GEMM_BIG_DGRAD"); return v ? atoi(v) != 0 : true; }();
+        static const bool on = TTL_EXPERIMENT("TTL_GEMM_BIG_DGRAD", 1) != 0;
         if (!on || !a.aux || (size_t)((a.M + 127) / 128) * 128 > (size_t)a.padded) return false;
     }
     if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3) return false;
@@ -519,15 +514,15 @@ bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
 hipError_t launch_gemm_big(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
     if (gemm_huge_applicable(epi, a)) return launch_gemm_huge(epi, a, s);     // q/k/v, fc1: 256 x 256 tiles on four waves (gemm_huge.hip)
     // Tile height (TTL_GEMM_BIG_MT), ring depth, tile order, resident blocks: tuned in situ, see DESIGN.md §3.1
-    static const int mt_env = env_int("TTL_GEMM_BIG_MT", 5);
-    static const int st_env = env_int("TTL_GEMM_BIG_STAGES", 0);
-    static const int order_env = env_int("TTL_GEMM_BIG_ORDER", -1);
-    static const int blocks_env = env_int("TTL_GEMM_BIG_BLOCKS", 0);
+    static const int mt_env = TTL_EXPERIMENT("TTL_GEMM_BIG_MT", 5);
+    static const int st_env = TTL_EXPERIMENT("TTL_GEMM_BIG_STAGES", 0);
+    static const int order_env = TTL_EXPERIMENT("TTL_GEMM_BIG_ORDER", -1);
+    static const int blocks_env = TTL_EXPERIMENT("TTL_GEMM_BIG_BLOCKS", 0);
     const int cus = device_cu_count();
     if (!cus) return hipErrorInvalidDevice;
     int mt = mt_env;
     // TTL_GEMM_BIG_MT_WIDE (experiment r05m): another tile height for the wide, short-K launches only (QKV, fc1, MLP dgrad is separate)
-    static const int mt_wide = env_int("TTL_GEMM_BIG_MT_WIDE", 0);
+    static const int mt_wide = TTL_EXPERIMENT("TTL_GEMM_BIG_MT_WIDE", 0);
     if (mt_wide && a.N >= 2304 && a.K <= 1024) mt = mt_wide;
     if ((size_t)((a.M + 32 * mt - 1) / (32 * mt)) * 32 * mt > (size_t)a.padded) mt = 5;   // a.padded = rows every output buffer has
     if ((size_t)((a.M + 159) / 160) * 160 > (size_t)a.padded) return hipErrorInvalidValue;

@@ -335,7 +335,7 @@ hipError_t launch_huge_t(const GemmArgs& a, int max_blocks, hipStream_t s) {
     if (e != hipSuccess) return e;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     // tile order: measured neutral (profiles/r05_experiments.txt r05p: what the other orders save is re-fetched from the Infinity Cache)
-    static const int order_env = [] { const char* v = getenv("TTL_GEMM_HUGE_ORDER"); return v ? atoi(v) : 0; }();
+    static const int order_env = TTL_EXPERIMENT("TTL_GEMM_HUGE_ORDER", 0);
     const int order = (ntm >= 8) ? order_env : 0;
     const int nslots = order ? 8 * ((ntm + 7) / 8) * ntn : ntm * ntn;
     int grid = nslots < max_blocks ? nslots : max_blocks;
@@ -351,25 +351,25 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // In situ (tools/r05_huge_sweep.sh, fp16, three episodes in flight): q/k/v +1.1 % images/s and the GEMM class one at a time
     // 2.883 -> 2.850 ms; fc1 +0.2 % and 2.883 -> 2.99 ms (600 tiles = three rounds of 256, two 77-MB outputs per launch): fc1 stays
     // on gemm_big.hip, its epilogues here are kept for the tests and for other shapes.
-    static const int mode = [] { const char* v = getenv("TTL_GEMM_HUGE"); return v ? atoi(v) : 2; }();
+    static const int mode = ttl_switch(SW_GEMM_HUGE);
     // TTL_GEMM_HUGE_DGRAD=1: the MLP dgrad (EPI_GELU_BWD, N = F) too — measured slower (95.9 vs 86.1 us one at a time, no change in situ:
     // its u tile has to be read behind the last MFMAs, profiles/r05_experiments.txt r05q): off
-    static const int dgrad = [] { const char* v = getenv("TTL_GEMM_HUGE_DGRAD"); return v ? atoi(v) : 0; }();
+    static const int dgrad = TTL_EXPERIMENT("TTL_GEMM_HUGE_DGRAD", 0);
     if (mode <= 0) return false;
     // The N = 768 / 1024 launches (out_proj, fc2 and their dgrads: fp32 outputs, residual): 150 tiles of 256 x 256 leave 106 CUs idle and
     // take 40 % longer than the 160 x 256 kernel's 237 tiles one at a time — but 11-31 % less CU-time, and with other episodes in flight
     // (GemmArgs::concurrent >= 2: the caller said so, ttl_ctx_set_concurrency) those CUs run their kernels: +2.5 % images/s at three
     // episodes in flight, +1.1 % at two; below tiles for half of the CUs it loses (32 views: -1 %, 8 views: -8 %).
     // TTL_GEMM_HUGE_NARROW: -1 = that rule (default), 0 = never, 1 = whenever the launch has the tiles.  profiles/r05_narrow_ab_fp16.txt
-    static const int narrow = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW"); return v ? atoi(v) : -1; }();
+    static const int narrow = ttl_switch(SW_GEMM_HUGE_NARROW);
     if ((epi == EPI_F32 || epi == EPI_RESID_F32 || epi == EPI_OP) && !a.hm_T && a.N < 2304) {
         if (narrow == 0 || (narrow < 0 && a.concurrent < 2)) return false;
         if (a.M < 1024 || a.N % BN || a.K % BK || a.K / BK < 3 || a.amap || a.cmap || a.c2map || a.splits > 1) return false;
         const size_t lim2 = (size_t)1 << 31;
         if ((size_t)a.M * a.lda * sizeof(op_t) >= lim2 || (size_t)a.N * a.ldb * sizeof(op_t) >= lim2 || (size_t)a.M * a.ldc * 4 >= lim2) return false;
         if (epi == EPI_RESID_F32 && (!a.resid || (size_t)a.M * a.ldr * 4 >= lim2)) return false;
-        static const int mink = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW_MINK"); return v ? atoi(v) : 0; }();
-        static const int maxk = [] { const char* v = getenv("TTL_GEMM_HUGE_NARROW_MAXK"); return v ? atoi(v) : 1 << 30; }();
+        static const int mink = TTL_EXPERIMENT("TTL_GEMM_HUGE_NARROW_MINK", 0);
+        static const int maxk = TTL_EXPERIMENT("TTL_GEMM_HUGE_NARROW_MAXK", 1 << 30);
         const long cus2 = device_cu_count();
         return cus2 > 0 && (long)((a.M + BM - 1) / BM) * (a.N / BN) * 2 >= cus2 && a.K >= mink && a.K <= maxk;
     }
@@ -382,7 +382,7 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // more CUs busy (8 views: 63 tiles here, 90 there: 1157 vs 1168 images/s).  Partial LATER rounds are not held against it: ViT-L/14's
     // 780 tiles (76 % of four rounds) are 5.7 % slower one at a time (107.9 vs 102.1 us) and still +0.8 % images/s with three episodes
     // in flight, where a launch costs tiles x time per tile (tools/r05_huge_fill_ab.sh).  TTL_GEMM_HUGE_MIN_FILL: percent of one round.
-    static const int min_fill = [] { const char* v = getenv("TTL_GEMM_HUGE_MIN_FILL"); return v ? atoi(v) : 85; }();
+    static const int min_fill = ttl_switch(SW_GEMM_HUGE_MIN_FILL);
     const long cus = device_cu_count();
     if (cus <= 0) return false;
     const long tiles = (long)((a.M + BM - 1) / BM) * (a.N / BN);
@@ -396,7 +396,7 @@ bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
 }
 
 hipError_t launch_gemm_huge(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
-    static const int blocks_env = [] { const char* v = getenv("TTL_GEMM_HUGE_BLOCKS"); return v ? atoi(v) : 0; }();
+    static const int blocks_env = TTL_EXPERIMENT("TTL_GEMM_HUGE_BLOCKS", 0);
     const int cus = device_cu_count();
     if (!cus) return hipErrorInvalidDevice;
     const int max_blocks = blocks_env > 0 ? blocks_env : cus;

@@ -393,7 +393,7 @@ hipError_t launch_lora_wgrad(const WgradList& L0, int M, int D, int r, float* pa
     // instantiation covers a contiguous range of the list.
     WgradList L = {};
     bool used[WGRAD_MAX] = {};
-    static const int merge = [] { const char* v = getenv("TTL_WGRAD_MERGE"); return v ? atoi(v) : 0; }();
+    static const int merge = TTL_EXPERIMENT("TTL_WGRAD_MERGE", 0);
     int nm = 0;
     if (r == 16 && merge)
         for (int i = 0; i < L0.n; ++i) {

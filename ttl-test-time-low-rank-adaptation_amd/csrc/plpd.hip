@@ -119,6 +119,17 @@ __global__ __launch_bounds__(256) void plpd_resize_kernel(const float* __restric
     out[i] = acc;
 }
 
+// torch.argmax's order (deyo.py:138): NaN counts as the maximum, the first index wins among equals.  A candidate row that is all
+// -inf or holds a NaN does reach this kernel (the rank-based top-k of head_loss.hip gives a NaN entropy rank 0): the arg-max must
+// still be an index < K.  INT_MAX marks "no element seen" (lanes beyond K) and never wins.
+__device__ __forceinline__ bool argmax_better(float v, int a, float mx, int am) {
+    if (a == 0x7fffffff) return false;
+    if (am == 0x7fffffff) return true;
+    const bool vn = v != v, mn = mx != mx;
+    if (vn || mn) return vn && (!mn || a < am);
+    return v > mx || (v == mx && a < am);
+}
+
 // keep[ids1[b]] = softmax(z[ids1[b]])[c] - softmax(z'[b])[c] > thr,  c = argmax z[ids1[b]] (first maximum, like torch.argmax);
 // one block per candidate view; `keep` [N] was zeroed by the launcher
 __global__ __launch_bounds__(256) void plpd_keep_kernel(const float* __restrict__ z, const float* __restrict__ zp, const long long* __restrict__ idx,
@@ -134,19 +145,20 @@ __global__ __launch_bounds__(256) void plpd_keep_kernel(const float* __restrict_
     int am = 0x7fffffff;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float v = row[k];
-        if (v > mx) { mx = v; am = k; }
+        if (argmax_better(v, k, mx, am)) { mx = v; am = k; }
         mxp = fmaxf(mxp, rowp[k]);
     }
     // block arg-max with the lowest index among equals
     for (int o = 32; o > 0; o >>= 1) {
         const float v = __shfl_xor(mx, o, 64); const int a = __shfl_xor(am, o, 64);
-        if (v > mx || (v == mx && a < am)) { mx = v; am = a; }
+        if (argmax_better(v, a, mx, am)) { mx = v; am = a; }
         mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64));
     }
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; redi[threadIdx.x >> 6] = am; }
     __syncthreads();
     float bm = red[0]; int ba = redi[0];
-    for (int w = 1; w < 4; ++w) if (red[w] > bm || (red[w] == bm && redi[w] < ba)) { bm = red[w]; ba = redi[w]; }
+    for (int w = 1; w < 4; ++w) if (argmax_better(red[w], redi[w], bm, ba)) { bm = red[w]; ba = redi[w]; }
+    if ((unsigned)ba >= (unsigned)K) ba = 0;      // (K >= 1: unreachable; the read of rowp[ba] below must stay inside the row whatever the data)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mxp;
     __syncthreads();

@@ -33,6 +33,7 @@ import torch.nn.init as init
 
 from . import synth
 from .config import get_config, get_text_config
+from . import _lib
 from ._lib import TtlError
 from .engine import TTLEngine, TextTowerEngine
 
@@ -187,7 +188,7 @@ class _PlpdTextForward:
 
 
 def build_text_mode_engine(vcfg, tcfg, vision_state, text_state, prompts, logit_scale_exp, device, max_views, max_prompts,
-                           precision="bf16"):
+                           precision=None):
     """Image context (no adapters) + text-tower context with prompts and logit scale set; LoRA still unbound."""
     img = TTLEngine(vcfg, max_views, max_prompts, device, precision)      # (class capacity: the PLPD forward scores views on it)
     img.load_weights(vision_state)
@@ -375,7 +376,7 @@ class ClipTestTimeTuning(nn.Module):
 
     def __init__(self, device, classnames, batch_size, criterion='cosine', arch="ViT-B/16", n_ctx=16, ctx_init=None,
                  ctx_position='end', learned_cls=False, layer_range=[9, 11], init_method=None, lora_encoder='text',
-                 rank=16, max_views=64, max_classes=1000, weight_seed=0, precision="bf16",
+                 rank=16, max_views=64, max_classes=1000, weight_seed=0, precision=None,
                  target_modules=("q_proj", "v_proj")):
         """``target_modules``: attention projections that carry an adapter — the reference hard-codes ["q_proj", "v_proj"] in
         its LoraConfig (clip/custom_clip.py:586); "k_proj" / "out_proj" add the adapters BASELINE.json's north_star names."""
@@ -388,7 +389,9 @@ class ClipTestTimeTuning(nn.Module):
         self.cfg = cfg = cfg.replace(rank=rank, layer_lo=layer_range[0], layer_hi=layer_range[1], lora_targets=tuple(target_modules))
         self.layer_range = list(layer_range)
         self.criterion = criterion
-        self.precision = precision   # MFMA operand dtype: "bf16" (default) or "fp16" (reference's autocast dtype)
+        # MFMA operand dtype: None = _lib.DEFAULT_PRECISION = "fp16" (the reference's autocast dtype, the build inside the 1e-3
+        # tolerance); "bf16" and "strict" are opt-in
+        self.precision = _lib.resolve_precision(precision)
         self.max_views = max(int(batch_size or 0), int(max_views))
         self.max_classes = max(int(max_classes), len(classnames))
         clip_model, vis_state, tokenizer = _build_clip(cfg, os.environ.get(CLIP_WEIGHTS_ENV), weight_seed)

@@ -370,9 +370,11 @@ class EpisodeRunner:
             return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
         from .deyo import draw_plpd_perms, plpd_candidates
         nc = plpd_candidates(self.args, views.shape[0], self.eng.n_classes)
-        if not nc:
+        if nc is None:
             raise NotImplementedError("the first-stage selection count is data-dependent here (threshold mode with more than 1000 "
-                                      "classes) or zero: use ttl.test_time_tuning (step-wise path)")
+                                      "classes): use ttl.test_time_tuning (step-wise path)")
+        if nc == 0:      # int(N * selection_p) == 0: the reference returns before the PLPD stage and the update (deyo.py:110-113)
+            return self.eng.episode(views, self.snap, m._opt_m, m._opt_v, **self.kw)
         text = m.lora_encoder == 'text'
         perm = draw_plpd_perms(self.plpd, self.kw["n_updates"], nc, views.shape[-1], self.eng.device)
         st = self.eng.plpd_struct(self.plpd, perm, nc, None if text else m._aux_engine()) if not text else \
@@ -391,7 +393,7 @@ class EpisodePipeline:
     """
 
     def __init__(self, cfg, weights, lora_names, lora_init, text_features, logit_scale_exp, device, n_streams=2,
-                 max_views=64, precision="bf16", engine_factory=None, n_classes=None, use_graph=False):
+                 max_views=64, precision=None, engine_factory=None, n_classes=None, use_graph=False):
         """``engine_factory`` (optional): callable returning a ready engine (weights loaded, peer features /
         prompts set, LoRA unbound) with ``bind_lora`` / ``episode`` / ``close`` — used for
         ``--lora_encoder text`` (custom_clip.build_text_mode_engine); default: an image-tower TTLEngine."""

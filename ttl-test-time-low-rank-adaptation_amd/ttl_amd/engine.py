@@ -31,12 +31,13 @@ def _stream():
 class TTLEngine:
     """Owns the HIP context (frozen bf16 weights + activation arena) of one image tower."""
 
-    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device, precision: str = "bf16", share_from=None):
-        """precision: MFMA operand dtype — "bf16" (default) or "fp16" (the reference's autocast dtype).
+    def __init__(self, cfg: VitConfig, max_views: int, max_classes: int, device, precision: str = None, share_from=None):
+        """precision: MFMA operand dtype — None = _lib.DEFAULT_PRECISION = "fp16" (the reference's autocast dtype; within 1e-3 of the
+        reference's logits), "bf16" (4e-3) or "strict" (fp32 operands, test build) on request.
         share_from: an engine of the same model whose weights are loaded — this engine then reads that engine's frozen
         weight images instead of holding copies (ttl_ctx_create_shared; the reference has ONE model per process,
         ttl.py:178-179); ``load_weights`` must not be called on it and ``share_from`` must stay open while it is in use."""
-        self.precision = precision
+        self.precision = precision = _lib.resolve_precision(precision)
         self.lib = _lib.load(precision)
         self.cfg = cfg
         self.device = torch.device(device)
@@ -89,6 +90,10 @@ class TTLEngine:
     @property
     def workspace_bytes(self):
         return int(self.lib.ttl_workspace_bytes(C.byref(self._ccfg)))
+
+    def allocated_bytes(self):
+        """Device bytes this context holds right now (ttl_ctx_allocated_bytes)."""
+        return int(self.lib.ttl_ctx_allocated_bytes(self._h))
 
     # ------------------------------------------------------------------ setup
     def load_weights(self, state: dict):
@@ -410,7 +415,7 @@ class TextTowerEngine(TTLEngine):
     attention over the prompt tokens whose q/v LoRA is the thing being tuned.  ``max_prompts`` bounds K,
     ``max_views`` the number of image views whose features it scores."""
 
-    def __init__(self, cfg, max_prompts: int, max_views: int, device, precision: str = "bf16"):
+    def __init__(self, cfg, max_prompts: int, max_views: int, device, precision: str = None):
         super().__init__(cfg, max_prompts, max_views, device, precision)
         self.n_prompts = 0
         self.n_views = 0

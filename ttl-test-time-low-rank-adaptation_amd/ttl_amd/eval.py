@@ -59,7 +59,9 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
         from .deyo import plpd_candidates, plpd_spec
         deyo = bool(args.deyo_selection) and args.lora_encoder != 'prompt'
         n_cls0 = int(model.prompt_learner.tokenized_prompts.shape[0]) if model.lora_encoder == 'text' else int(model.text_features.shape[0])
-        ok = deyo and not getattr(args, "reweight_plpd", 0) and plpd_candidates(args, 64, n_cls0) and os.environ.get("TTL_PLPD_STEPWISE", "0") != "1"
+        # (fused stage: the first-stage candidate count must be known without looking at the logits — top-rho mode, or threshold
+        #  mode with K <= 1000 classes; the count itself is taken per image from the loader's actual view count below)
+        ok = deyo and not getattr(args, "reweight_plpd", 0) and plpd_candidates(args, 1, n_cls0) is not None and os.environ.get("TTL_PLPD_STEPWISE", "0") != "1"
         if not ok:
             return _host_loop_eval(val_loader, model, optimizer, optim_state, scaler, args, rank, world, gpu_augmenter)
         plpd = plpd_spec(args)
@@ -113,7 +115,11 @@ def test_time_adapt_eval(val_loader, model, model_state, optimizer, optim_state,
         tgt = torch.as_tensor(target).reshape(-1)[:1].to(dev, dtype=torch.int64)     # the device-side hit count reads an int64 label
         if plpd is not None:
             from .deyo import plpd_candidates
-            pipe.submit(images, target=tgt, plpd=dict(spec=plpd, n_candidates=plpd_candidates(args, images.shape[0], n_cls)), **kw)
+            nc = plpd_candidates(args, images.shape[0], n_cls)
+            if nc:
+                pipe.submit(images, target=tgt, plpd=dict(spec=plpd, n_candidates=nc), **kw)
+            else:       # int(N * selection_p) == 0 (fewer than 10 views at rho 0.1): the reference returns before the PLPD stage and
+                pipe.submit(images, target=tgt, **kw)       # the update (deyo.py:110-113); the episode's empty top-rho selection does the same
         else:
             pipe.submit(images, target=tgt, **kw)
         if progress is not None:
@@ -241,13 +247,16 @@ def main():
     ap.add_argument("--row_start", type=int, default=56)
     ap.add_argument("--column_start", type=int, default=56)
     ap.add_argument("--streams", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "strict"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "strict"],
+                    help="MFMA operand dtype; default: ttl_amd._lib.DEFAULT_PRECISION = fp16 (the reference's autocast dtype), or TTL_PRECISION")
     ap.add_argument("--gpu_views", type=int, default=0, help="1: decoded uint8 images in, views generated on the GPU")
     ap.add_argument("--lora_encoder", default="image", choices=["image", "text"])
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic data and of the GPU view generator's crop boxes")
     ap.add_argument("--resume_file", default=None, help="prefix of the per-rank progress files (driver.ShardProgress): a run that "
                     "is started again with the same arguments continues after the last recorded image of every rank")
     a = ap.parse_args()
+    from . import _lib
+    a.precision = _lib.resolve_precision(a.precision)      # the resume tag and the result line name the build that ran
     rank, local, world = dist_env()
     from .driver import ShardProgress, pin_to_gpu_numa_node
     pin_to_gpu_numa_node(local, world)          # before the first GPU call: host threads next to the device's PCIe root

@@ -68,7 +68,7 @@ def draw_boxes(height, width, n_views, generator=None):
     return torch.tensor(rows, dtype=torch.int32)
 
 
-def make_views(image_u8_hwc, boxes, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None, precision="bf16"):
+def make_views(image_u8_hwc, boxes, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None, precision=None):
     """image_u8_hwc: CUDA uint8 [H,W,3]; boxes: int32 [N,5] (host or device).  Returns the normalised
     fp32 batch [N,3,size,size] on the image's device, enqueued on the current stream."""
     if not image_u8_hwc.is_cuda or image_u8_hwc.dtype != torch.uint8 or image_u8_hwc.dim() != 3 or image_u8_hwc.shape[2] != 3:
@@ -106,7 +106,7 @@ class GpuAugMixAugmenter:
     With ``seed`` set, item ``index`` draws its boxes from ``item_generator(seed, index)`` (world-size invariant);
     without, from ``generator`` / the global torch RNG in call order like the reference's host pipeline."""
 
-    def __init__(self, n_views=63, size=224, generator=None, precision="bf16", seed=None):
+    def __init__(self, n_views=63, size=224, generator=None, precision=None, seed=None):
         self.n_views, self.size, self.generator, self.precision, self.seed = n_views, size, generator, precision, seed
 
     def boxes(self, height, width, index=None):
