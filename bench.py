@@ -595,15 +595,25 @@ def main():
         """Current shader clock (MHz) of this rank's GPU from sysfs, best effort (None when the node is not readable)."""
         import glob
         import re
-        out = []
+        out, mine = {}, None
+        try:        # the PCI address of THIS rank's device picks its card node (a box shows the nodes of every GPU of the host)
+            pr = torch.cuda.get_device_properties(dev)
+            mine = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
         for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
             try:
+                addr = os.path.basename(os.path.realpath(os.path.dirname(f)))
                 cur = [l for l in open(f).read().splitlines() if l.rstrip().endswith("*")]
                 m = re.search(r"(\d+)\s*Mhz", cur[0], re.I) if cur else None
-                out.append(int(m.group(1)) if m else None)
+                out[addr] = int(m.group(1)) if m else None
             except Exception:
-                out.append(None)
-        return out or None
+                pass
+        if mine is not None:
+            hit = [v for k, v in out.items() if k.lower().startswith(mine)]
+            if hit:
+                return {"this_gpu": hit[0], "pci": mine}
+        return {"all_card_nodes": out} if out else None
 
     def sustained_run(pipe, seconds):
         """The same pipeline, `seconds` of continuous load with NO fence inside (what a 50 000-image evaluation looks like; the timed

@@ -178,6 +178,13 @@ int ttl_ctx_tpt_select_loss(ttl_ctx* ctx, const float* logits, int n_views, int 
  * post-LN -> layers layer_hi..layer_lo, writing dA/dB of q_proj and v_proj into the bound grads
  * buffer (overwritten, i.e. optimizer.zero_grad() + backward, deyo.py:185-186). */
 int ttl_vit_backward_lora(ttl_ctx* ctx, const float* dlogits, int n_views, void* stream);
+/* on != 0: the dlogits handed to the backward entries of this context ALREADY carry the caller's loss scale — the reference's own
+ * `scaler.scale(loss).backward()` (deyo.py:185, ttl.py:222 GradScaler(init_scale=1000)) running through the autograd node of
+ * ClipTestTimeTuning.forward: the context's own loss scale is then NOT applied on top (2^10 x 1000 overflows the fp16 backward),
+ * the gradients come back scaled like dlogits — torch's `scaler.step(optimizer)` unscales them and looks for inf/nan, exactly as in
+ * the reference.  Off (default): the context scales and unscales by itself (fused episode, step-wise host loop).  ttl_episode*
+ * refuse to run while it is on. */
+int ttl_ctx_backward_prescaled(ttl_ctx* ctx, int on);
 /* The same backward when the caller knows that dlogits is zero outside the n_selected views idx lists (device memory, distinct view
  * numbers < n_views) — the list a top-k selection produced: deyo.py:105 `argsort(entropys)[:int(N * selection_p)]` (--filter_ent 1),
  * ttl.py:52 select_confident_samples (TPT).  Rows of the other views contribute exactly nothing to any LoRA gradient, so the backward

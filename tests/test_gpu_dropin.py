@@ -127,6 +127,10 @@ def test_reference_shaped_loop(name, precision):
     kw = episode_kwargs(g)
     tol = dict(SURFACE_TOL[precision])
     n_up = kw["n_updates"]
+    if n_up > 1 and name.startswith("tiny") and precision == "fp16":
+        # the D = 128 toys after several sign-like AdamW updates (Q11): 1.7e-3 (two TPT updates) where the full-size four-update
+        # fixture sits at 2.6e-4; the engine-level multi-update tests use the same 3 x tolerance
+        tol["logits1"] = 3e-3
     args = ref_args(filter_ent=1 if (kw["mode"] == "topk" and kw["objective"] == "deyo") else 0,
                     deyo_selection=(kw["objective"] == "deyo"), lr=kw["lr"], selection_p=kw["rho"],
                     tta_steps={1: 1, 4: 2, 2: 2}[n_up])
@@ -204,9 +208,14 @@ def test_fused_runner_equals_stepwise_surface():
     assert torch.equal(a, b)
 
 
-def test_reference_formulation_through_autograd():
-    """deyo.py:97-108,175-188 verbatim in torch on top of model(x): exercises the autograd hook."""
-    g, cfg, model, opt, opt_state, x = build("tiny_deyo")
+@pytest.mark.parametrize("name", ["tiny_deyo", "b16_n8_k10"])
+def test_reference_formulation_through_autograd(name):
+    """deyo.py:97-108,175-188 verbatim in torch on top of model(x): exercises the autograd hook, on the surface's default (fp16) build
+    with the reference's GradScaler(init_scale=1000) (ttl.py:222).  The scaled loss reaches the HIP backward through torch's graph, so
+    the context's own 2^10 loss scale must stay out of it (ttl_ctx_backward_prescaled): the gradients torch's scaler unscales are
+    the reference's, at the fp16 build's gradient tolerance."""
+    g, cfg, model, opt, opt_state, x = build(name)
+    assert model.precision == "fp16" or os.environ.get("TTL_PRECISION")
     with torch.no_grad():
         model.LoRA_reset()
     opt.load_state_dict(opt_state)
@@ -228,12 +237,14 @@ def test_reference_formulation_through_autograd():
         gref = g["grad/" + k]
         p = dict(model.named_parameters())["image_encoder." + k]
         if np.abs(gref).max() > 0:
-            assert max_rel(p.grad.cpu().numpy(), gref) < 4e-2, k          # grads were unscaled by the GradScaler
+            assert torch.isfinite(p.grad).all(), k
+            assert max_rel(p.grad.cpu().numpy(), gref) < 4e-3, k          # grads were unscaled by the GradScaler (fp16 build: 4 x 1e-3, as the engine-level tests)
+    assert scaler.get_scale() == 1000.0                                   # no inf/nan was found: the step was taken, the scale kept
     frac_bad = np.mean([float((np.abs(lora1[k] - g["lora1/" + k]) > 1e-3).mean()) for k in lora1])
     assert frac_bad < 0.05, frac_bad
     with torch.no_grad():
         out = model(x[:1])
-    assert max_rel(out.cpu().numpy(), g["logits1"]) < 3e-2
+    assert max_rel(out.cpu().numpy(), g["logits1"]) < 1e-3
 
 
 def test_eval_loop_matches_per_image_surface():

@@ -174,7 +174,7 @@ def test_workspace_bytes_equals_what_a_context_allocates(arch, n, k, targets):
         cfg = cfg.replace(lora_targets=targets)
     for prec in ("fp16", "strict"):
         eng = TTLEngine(cfg, n, k, "cuda:0", precision=prec)
-        assert eng.allocated_bytes() == eng.workspace_bytes() > 0, (prec, eng.allocated_bytes(), eng.workspace_bytes())
+        assert eng.allocated_bytes() == eng.workspace_bytes > 0, (prec, eng.allocated_bytes(), eng.workspace_bytes)
         eng.close()
 
 

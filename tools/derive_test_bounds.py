@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""measured.json (written by a `TTL_RECORD_BOUNDS=... pytest -m gpu` run on MI355X) -> tests/golden/bounds.json.
+"""measured.json (written by a `TTL_RECORD_BOUNDS=... pytest -m gpu` run on MI355X) -> tests/golden/bounds.json
+(merged into the measurements already there; `--replace` to start over).
 
 bound = measured x 1.3, rounded up to 3 significant digits; quantities that measure (almost) zero get a floor of 1e-6 so that a
 last-bit change of a summation order cannot fail them.  tests/bounds.py applies them on top of each assertion's documented ceiling."""
@@ -22,6 +23,12 @@ def up3(v):
 def main():
     src = sys.argv[1]
     meas = json.load(open(src))
+    dst0 = os.path.join(ROOT, "tests", "golden", "bounds.json")
+    if "--replace" not in sys.argv[2:] and os.path.exists(dst0):
+        # default: MERGE — keys measured in this recording run replace their old value, keys it did not touch (a partial run, e.g.
+        # `pytest tests/test_gpu_dropin.py`) keep theirs; --replace starts from the recording alone
+        old = json.load(open(dst0)).get("measured", {})
+        meas = {**old, **meas}
     out = {"note": "tools/derive_test_bounds.py: bound = measured-on-MI355X x %.1f (3 significant digits, floor %g); "
                    "regenerate after any kernel change that moves a summation order" % (MARGIN, FLOOR),
            "margin": MARGIN, "measured": {k: meas[k] for k in sorted(meas)},

@@ -63,6 +63,8 @@ if __name__ == "__main__":
         child(sys.argv[1])
         sys.exit(0)
     prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+    if prec == "fp16":      # TTL_GEMM_HUGE_DGRAD is a closed experiment: only the -DTTL_EXPERIMENTS build of the fp16 library reads it
+        os.environ.setdefault("TTL_HIP_LIB_FP16", os.path.join(ROOT, "ttl-test-time-low-rank-adaptation_amd", "ttl_amd", "libttl_hip_fp16_exp.so"))
     for mode, label in (("1", "gemm_huge.hip (256 x 256, four waves)"), ("0", "gemm_big.hip (160 x 256, eight waves)"), ("1", "gemm_huge.hip again")):
         print(f"---- TTL_GEMM_HUGE={mode}: {label}   [{prec}]", flush=True)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), prec, "--child"], env=dict(os.environ, TTL_GEMM_HUGE=mode, TTL_GEMM_HUGE_MIN_FILL="0", TTL_GEMM_HUGE_DGRAD="1"))

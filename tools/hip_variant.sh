@@ -11,12 +11,15 @@ mkdir -p ../../tools/_diag
 P=${TTL_PRECISION:-fp16}
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fvisibility=hidden"
 PFX=""
-if [ "$P" = fp16 ]; then FL="$FL -DTTL_OPERAND_FP16"; PFX="fp16_"; fi
+# fp16 variants are made of the EXPERIMENTS objects (build/exp: -DTTL_EXPERIMENTS, csrc/common.hpp) so that the closed A/B switches stay
+# readable in an A/B library; the product builds compile them out
+OBJ=$P
+if [ "$P" = fp16 ]; then FL="$FL -DTTL_OPERAND_FP16 -DTTL_EXPERIMENTS"; PFX="fp16_"; OBJ=exp; fi
 for n in "$@"; do
   t=${PFX}${f}_$(echo $n | tr '=' '_')
   ( /opt/rocm/bin/hipcc $FL -D$n -c $f.hip -o ../../tools/_diag/$t.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o ../../tools/_diag/libttl_hip_$t.so \
-     ../../tools/_diag/$t.o $(ls build/$P/*.o | grep -v /$f.o) ) &
+     ../../tools/_diag/$t.o $(ls build/$OBJ/*.o | grep -v /$f.o) ) &
 done
 wait
 ls ../../tools/_diag/libttl_hip_${PFX}${f}_*.so

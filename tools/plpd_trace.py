@@ -39,6 +39,7 @@ def summarize(d):
 if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
     sys.exit(1 if summarize(sys.argv[2]) else 0)
 
+import time
 import torch
 from ttl_amd import synth
 from ttl_amd.config import get_config, trainable_names
@@ -57,6 +58,16 @@ torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 n = 30
+host = {"draw": 0.0, "struct": 0.0, "n": 0}
+if "--host-timing" in sys.argv:      # where the host's time per image goes: the permutation draw, and all of _plpd_struct (draw + staging copy)
+    import ttl_amd.deyo as _D
+    _draw, _struct = _D.draw_plpd_perms, pipe._plpd_struct
+    def draw(*a_, **k_):
+        t = time.perf_counter(); r = _draw(*a_, **k_); host["draw"] += time.perf_counter() - t; return r
+    def struct(*a_, **k_):
+        t = time.perf_counter(); r = _struct(*a_, **k_); host["struct"] += time.perf_counter() - t; host["n"] += 1; return r
+    _D.draw_plpd_perms, pipe._plpd_struct = draw, struct
+    print("torch threads:", torch.get_num_threads(), "cpus:", os.cpu_count(), flush=True)
 for i in range(6):       # warm-up: auxiliary contexts, graph capture
     pipe.submit(views[i % 3], target=tgt, want_output=False, plpd=dict(spec=spec, n_candidates=64), n_updates=1)
 pipe.synchronize()
@@ -66,3 +77,5 @@ for i in range(n):
 pipe.synchronize()
 print(f"{aug}: {n / (time.perf_counter() - t0):.1f} images/s with the PLPD stage (64 views, K=200, 3 episodes in flight, {'graph replay' if graph else 'plain launches'})", flush=True)
 pipe.close()
+if host["n"]:
+    print(f"   host per image: permutation draw {1e3 * host['draw'] / host['n']:.2f} ms, _plpd_struct in all {1e3 * host['struct'] / host['n']:.2f} ms", flush=True)

@@ -127,6 +127,8 @@ struct ttl_ctx {
     float *plpd_tf = nullptr, *plpd_tfT = nullptr, *plpd_lkn = nullptr, *plpd_lnk = nullptr;
     // GradScaler state (device) and policy (host): ttl.py:222, deyo.py:186-188
     ScalerState sc{nullptr, nullptr};
+    float* sc_unit = nullptr;       // {1, 1, 1, 1}: what the backward reads instead of sc.f while `prescaled` is set
+    bool prescaled = false;         // ttl_ctx_backward_prescaled: dlogits already carry the caller's loss scale (torch GradScaler on the autograd path)
     int sc_dynamic = 0; float sc_growth = 2.f, sc_backoff = 0.5f; int sc_interval = 2000;
     // Backward on the selected views only (top-k selections: deyo.py:105 filter_ent, ttl.py:52 TPT; TTL_BWD_COMPACT=0: off).  The loss
     // gradient is zero outside the int(n * rho) selected views, so their rows contribute nothing to any LoRA gradient: the saved
@@ -459,11 +461,13 @@ static int ctx_create_impl(const ttl_config* k, ttl_ctx* parent, ttl_ctx** out, 
     ALLOC(c->loss_scratch, 7 * nmax + 16, true);
     ALLOC(c->idx_buf, nmax, true); ALLOC(c->n_buf, 4, true); ALLOC(c->loss_buf, 4, true); ALLOC(c->H_buf, nmax, true);
     ALLOC(c->keep_buf, nmax, true); ALLOC(c->plpd_val, nmax, true);
-    ALLOC(c->sc.f, SC_NF, true); ALLOC(c->sc.i, SC_NI, true);
+    ALLOC(c->sc.f, SC_NF, true); ALLOC(c->sc.i, SC_NI, true); ALLOC(c->sc_unit, SC_NF, true);
     {   // fp16-operand build: dynamic loss scaling from 2^10 like the reference's GradScaler(init_scale=1000) (ttl.py:222);
         // bf16 needs no loss scale (scale 1, fixed) but keeps the whole-step skip on non-finite gradients
         const float init[SC_NF] = {TTL_GRAD_SCALE, 1.0f / TTL_GRAD_SCALE, 1.f, 1.f};
+        const float unit[SC_NF] = {1.f, 1.f, 1.f, 1.f};
         if (!dry) HIP_TRY(hipMemcpy(c->sc.f, init, sizeof init, hipMemcpyHostToDevice));
+        if (!dry) HIP_TRY(hipMemcpy(c->sc_unit, unit, sizeof unit, hipMemcpyHostToDevice));
         c->sc_dynamic = (TTL_GRAD_SCALE != 1.0f);
     }
     guard.ok = true;
@@ -722,7 +726,7 @@ static HeadArgs head_args(ttl_ctx* c, const float* h, float* feats_out, float* l
     a.WpT = c->wpT; a.Wp = c->wp; a.tfeat = c->tfeat; a.tfeatT = c->tfeatT; a.scale = c->scale;
     a.cls_mean = c->cls_mean; a.cls_rstd = c->cls_rstd; a.y = c->ycls; a.f = c->feat; a.logits = logits; a.feats_out = feats_out;
     a.tmp_e = c->head_te; a.tmp_d = c->head_td;
-    a.gscale = c->sc.f;
+    a.gscale = c->prescaled ? c->sc_unit : c->sc.f;
     return a;
 }
 
@@ -1253,8 +1257,9 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
                 }
             }
             if (Lo.n && Mo == M) { Lq.p[Lq.n++] = Lo.p[0]; Lq.p[Lq.n++] = Lo.p[1]; Lo.n = 0; }   // same row count: one launch
-            if (Lq.n) HIP_TRY(launch_lora_wgrad(Lq, M, D, r, c->wg_partial, s, c->sc.f, c->sc.i));
-            if (Lo.n) HIP_TRY(launch_lora_wgrad(Lo, Mo, D, r, c->wg_partial + (size_t)Lq.n * lora_wgrad_chunks(M) * r * D, s, c->sc.f, c->sc.i));
+            const float* scf = c->prescaled ? c->sc_unit : c->sc.f;
+            if (Lq.n) HIP_TRY(launch_lora_wgrad(Lq, M, D, r, c->wg_partial, s, scf, c->sc.i));
+            if (Lo.n) HIP_TRY(launch_lora_wgrad(Lo, Mo, D, r, c->wg_partial + (size_t)Lq.n * lora_wgrad_chunks(M) * r * D, s, scf, c->sc.i));
         }
         if (first) break;
         // ---- dx1 = [dq dk dv | dU]·[Wqkv | A]  ; dh_in = dh_mid + LN1^T(dx1)
@@ -1279,6 +1284,12 @@ static int backward_impl(ttl_ctx* c, const float* dlogits, int n, void* stream, 
 int ttl_vit_backward_lora(ttl_ctx* c, const float* dlogits, int n, void* stream) {
     if (c && c->text) return fail(TTL_ESTATE, "ttl_vit_backward_lora on a text-tower context (use ttl_text_backward_lora)");
     return backward_impl(c, dlogits, n, stream);
+}
+
+int ttl_ctx_backward_prescaled(ttl_ctx* c, int on) {
+    if (!c) return fail(TTL_EINVAL, "null ctx");
+    c->prescaled = on != 0;
+    return 0;
 }
 
 int ttl_ctx_set_concurrency(ttl_ctx* c, int episodes_in_flight) {
@@ -1436,6 +1447,7 @@ int ttl_episode(ttl_ctx* c, const ttl_episode_args* a, void* stream) {
     if (c->text) return fail(TTL_ESTATE, "ttl_episode on a text-tower context (use ttl_episode_text)");
     if ((a->target == nullptr) != (a->hits_out == nullptr)) return fail(TTL_EINVAL, "target and hits_out go together");   // before the first launch
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called");
+    if (c->prescaled) return fail(TTL_ESTATE, "ttl_ctx_backward_prescaled is on: the fused episode scales its own backward (switch it off first)");
     hipStream_t s = (hipStream_t)stream;
     int rc;
     const ttl_plpd_args* pl = a->plpd;
@@ -1553,6 +1565,7 @@ int ttl_episode_text(ttl_ctx* c, ttl_ctx* v, const ttl_episode_args* a, void* st
     if (!c->text || v->text) return fail(TTL_ESTATE, "ttl_episode_text(text_ctx, image_ctx, ...): wrong tower kinds");
     if ((a->target == nullptr) != (a->hits_out == nullptr)) return fail(TTL_EINVAL, "target and hits_out go together");   // before the first launch
     if (!c->lora_p) return fail(TTL_ESTATE, "ttl_bind_lora has not been called on the text context");
+    if (c->prescaled) return fail(TTL_ESTATE, "ttl_ctx_backward_prescaled is on: the fused episode scales its own backward (switch it off first)");
     if (c->n_prompts < 1) return fail(TTL_ESTATE, "ttl_set_prompts has not been called");
     if (a->n_views > c->c.max_classes) return fail(TTL_EINVAL, "n_views %d exceeds the text context's capacity %d", a->n_views, c->c.max_classes);
     if (v->E != c->E) return fail(TTL_EINVAL, "embed dims differ (%d vs %d)", v->E, c->E);

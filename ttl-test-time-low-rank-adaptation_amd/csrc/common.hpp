@@ -131,6 +131,26 @@ __device__ __forceinline__ float quick_gelu_grad_f(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
+// ---- in-kernel clock stamps (-DTTL_CLOCK_STAMPS: DIAGNOSTIC builds only, tools/r06_clock_stamps.sh; in the product build no stamp
+// executes).  MI355X_MICROARCH.md DVFS give-back item 6: clock held = d s_memtime / d s_memrealtime x 100 MHz.  Every workgroup keeps
+// its stamps in scalar registers and writes them ONCE, behind its last tile, into a buffer of their own that nothing else reads.
+#ifdef TTL_CLOCK_STAMPS
+struct TtlClockStamp { unsigned long long t0, r0, t1, r1, k0, kr0, k1, kr1; };     // whole kernel (t, r); K loop of the first tile (k, kr)
+#define TTL_STAMP_SLOTS 2048
+#define TTL_STAMP_DECL unsigned long long st_t0 = 0, st_r0 = 0, st_k0 = 0, st_kr0 = 0, st_k1 = 0, st_kr1 = 0
+#define TTL_STAMP_BEGIN() do { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TTL_STAMP_K0(first) do { if (first) { st_k0 = __builtin_amdgcn_s_memtime(); st_kr0 = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define TTL_STAMP_K1(first) do { if (first) { st_k1 = __builtin_amdgcn_s_memtime(); st_kr1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define TTL_STAMP_END(buf) do { if (threadIdx.x == 0 && blockIdx.x < TTL_STAMP_SLOTS) { \
+        buf[blockIdx.x] = TtlClockStamp{st_t0, st_r0, __builtin_amdgcn_s_memtime(), __builtin_amdgcn_s_memrealtime(), st_k0, st_kr0, st_k1, st_kr1}; } } while (0)
+#else
+#define TTL_STAMP_DECL
+#define TTL_STAMP_BEGIN() do {} while (0)
+#define TTL_STAMP_K0(first) do {} while (0)
+#define TTL_STAMP_K1(first) do {} while (0)
+#define TTL_STAMP_END(buf) do {} while (0)
+#endif
+
 // bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of the tile order for L2 reuse.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

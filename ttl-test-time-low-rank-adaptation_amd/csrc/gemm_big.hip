@@ -189,6 +189,10 @@ __device__ __forceinline__ bool tile_of(const TileMap& tm, int slot, int& rt, in
     return true;
 }
 
+#ifdef TTL_CLOCK_STAMPS
+__device__ TtlClockStamp g_big_stamps[TTL_STAMP_SLOTS];
+#endif
+
 template <int MT, int STAGES, int EPI>
 __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, const TileMap tm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,6 +320,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
         have = tile_of(tm, slot, rt, ct);
     }
     int row0 = rt * BM, col0 = ct * BN;
+    TTL_STAMP_DECL;
+    TTL_STAMP_BEGIN();
     setup(row0, col0);
     char* s0 = smem;
     char* s1 = smem + STAGE;
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
                     acc[mt][nt] = f32x4{biasv[nt], biasv[nt], biasv[nt], biasv[nt]};
             }
         load_frags(cur, 0, xf0, wf0);
+        TTL_STAMP_K0(first);
 
         // ---- steady state: step kt multiplies K-tile kt; requests kt+2 (3 stages: at the top, into the stage freed by
         // barrier kt-1; 2 stages: behind barrier kt, into the stage just read); one barrier per step
@@ -450,6 +457,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
             if constexpr (EPI == EPI_OP_HM) ecol = hm_col_base(a, (int)ecol);
             big_epilogue<EPI, MT>(a, acc, erow0 + wm * WM, ecol, lg, auxr);
         }
+        TTL_STAMP_K1(first);       // (gemm_big: the first tile's K loop AND its epilogue, which is interleaved with step nk-1)
         if (!more) break;
         slot = nslot;
         first = false;
@@ -458,6 +466,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const GemmArgs a, con
         if constexpr (STAGES == 3) { s0 = cur; s1 = nn; s2 = nxt; }
         else { s0 = cur; s1 = nxt; }
     }
+    TTL_STAMP_END(g_big_stamps);
 }
 
 template <int MT, int STAGES, int EPI>
@@ -498,6 +507,12 @@ unsigned qkv_hm_magic(int T, int limit) {
 }
 
 // rows the kernel may store for a launch of M rows with row tiles of 32*mt (unguarded epilogue)
+#ifdef TTL_CLOCK_STAMPS
+extern "C" __attribute__((visibility("default"))) int ttl_diag_clock_stamps_big(void* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamps), sizeof(TtlClockStamp) * TTL_STAMP_SLOTS);
+}
+#endif
+
 bool gemm_big_applicable(GemmEpi epi, const GemmArgs& a) {
     if (epi == EPI_PATCH) return false;                       // scattered output rows: guarded kernel of gemm.hip
     // MLP dgrad: its epilogue reads u (8*MT registers fetched ahead in gemm.hip).  Tried here with u fetched behind the last

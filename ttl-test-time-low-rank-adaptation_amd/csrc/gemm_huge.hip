@@ -60,15 +60,27 @@ __device__ __forceinline__ void wait_vm() {     // s_waitcnt vmcnt(N) lgkmcnt(0)
 }
 
 // 16 MFMAs of a sub-step: the 8 fragment reads lead, one per MFMA, in the order they are consumed; NV (0 or 4) DMA pieces follow
+// TTL_HUGE_SHAPE_PROBE (diagnostic builds only, tools/r06_shape_probe.sh; WRONG products): the same loop — fragment reads, DMA pieces,
+// waits, barriers, epilogue — with every v_mfma_f32_32x32x16 replaced by two v_mfma_f32_16x16x32 of the same operand registers into two
+// quarters of its accumulator: equal MFMA cycles, equal LDS / VMEM traffic.  Times what the OTHER bf16/f16 MFMA shape would do to the
+// clock the chip holds in THIS loop (MI355X_MICROARCH.md DVFS give-back item 7) before anyone rewrites the fragment layout for it.
+#ifdef TTL_HUGE_SHAPE_PROBE
+#define HUGE_MPS 2      // MFMA instructions per 32x32x16 of the real kernel
+#define ACC(mt, j, r) acc[mt][j][(r) >> 2][(r) & 3]
+#else
+#define HUGE_MPS 1
+#define ACC(mt, j, r) acc[mt][j][r]
+#endif
+
 template <int NV>
 __device__ __forceinline__ void mix() {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, HUGE_MPS, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
     if constexpr (NV >= 4) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+        for (int g = 0; g < 4; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 2 * HUGE_MPS, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
     } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * HUGE_MPS, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -89,6 +101,10 @@ __device__ __forceinline__ bool huge_tile_of(int order, int slot, int ntm, int n
     else { const int jr = j / ntn; rt = r0 + jr; ct = j - jr * ntn; }
     return true;
 }
+
+#ifdef TTL_CLOCK_STAMPS
+__device__ TtlClockStamp g_huge_stamps[TTL_STAMP_SLOTS];
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_huge_kernel(const GemmArgs a, int ntm, int ntn, int order, int nslots) {
@@ -139,7 +155,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(A0 + 2 * SLOT), 16, lane * 16, col0 * 4, 0, 0);
     };
 
+#ifdef TTL_HUGE_SHAPE_PROBE
+    f32x4 acc[4][4][4];
+#else
     f32x16 acc[4][4];
+#endif
     opx8 xf[2][4], wf[2][4];
     auto frags = [&](const char* sa, const char* sb, int s, int set) {
         const char* pa = sa + (fA0 ^ (s << 5));
@@ -154,7 +174,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mt][j] = MFMA32(xf[set][mt], wf[set][j], acc[mt][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+#ifdef TTL_HUGE_SHAPE_PROBE
+                acc[mt][j][2 * set] = MFMA16(xf[set][mt], wf[set][j], acc[mt][j][2 * set], 0, 0, 0);
+                acc[mt][j][2 * set + 1] = MFMA16(xf[set][mt], wf[set][j], acc[mt][j][2 * set + 1], 0, 0, 0);
+#else
+                acc[mt][j] = MFMA32(xf[set][mt], wf[set][j], acc[mt][j], 0, 0, 0);
+#endif
+            }
     };
 
     int slot = blockIdx.x;
@@ -165,6 +192,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (slot >= ntiles) return;
         row0 = rt * BM; col0 = ct * BN;
     }
+    TTL_STAMP_DECL;
+    TTL_STAMP_BEGIN();
     dma_bias(col0); dma_b(B0, col0, 0); dma_a(A0, row0, 0); dma_a(A0 + SLOT, row0, 1);
     bool first = true;
     for (;;) {
@@ -199,7 +228,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mt][j][r] = bv[j];
+                        for (int r = 0; r < 16; ++r) ACC(mt, j, r) = bv[j];
             } else {
                 auto init_half = [&](int g) {
 #pragma unroll
@@ -207,7 +236,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[2 * g + h][j][r] = bv[j] + rs[h][r][j];
+                            for (int r = 0; r < 16; ++r) ACC(2 * g + h, j, r) = bv[j] + rs[h][r][j];
                 };
                 init_half(0);
                 resid_bv = bv;
@@ -230,7 +259,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[2 + h][j][r] = resid_bv[j] + rs[h][r][j];
+                            for (int r = 0; r < 16; ++r) ACC(2 + h, j, r) = resid_bv[j] + rs[h][r][j];
                 }
             }
             frags(aC, bC, 1, 1);
@@ -250,11 +279,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             __builtin_amdgcn_sched_barrier(0);
             rotate();
         };
+        TTL_STAMP_K0(first);
         body(0, std::true_type{}, std::true_type{}, std::false_type{});
         int kt = 1;
         for (; kt + 2 < nk; ++kt) body(kt, std::true_type{}, std::true_type{}, std::true_type{});
         body(kt, std::true_type{}, std::false_type{}, std::true_type{}); ++kt;
         body(kt, std::false_type{}, std::false_type{}, std::true_type{});
+        TTL_STAMP_K1(first);
         // ---- every slot is free: the next tile's bias and first K-tiles go out before the last MFMAs and the stores of this one
         int nslot = slot + gridDim.x;
         int nrow0 = 0, ncol0 = 0;
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // (keeps the accumulator reads of 4 rows, not 64, live at once)
-                float v0 = acc[mt][0][r], v1 = acc[mt][1][r], v2 = acc[mt][2][r], v3 = acc[mt][3][r];
+                float v0 = ACC(mt, 0, r), v1 = ACC(mt, 1, r), v2 = ACC(mt, 2, r), v3 = ACC(mt, 3, r);
                 const int mrow = mt * 32 + 8 * (r >> 2) + (r & 3);
                 if constexpr (EPI == EPI_OP_HM) {
                     const unsigned m = (unsigned)(row0 + wm * 128 + 4 * lh + mrow);
@@ -326,6 +357,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         dma_a(A0 + SLOT, nrow0, 1);
         slot = nslot; row0 = nrow0; col0 = ncol0; first = false;
     }
+    TTL_STAMP_END(g_huge_stamps);
 }
 
 template <int EPI>
@@ -345,6 +377,13 @@ hipError_t launch_huge_t(const GemmArgs& a, int max_blocks, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef TTL_CLOCK_STAMPS
+// diagnostic export: the stamps of the LAST gemm_huge launch's workgroups (host buffer of TTL_STAMP_SLOTS x 8 uint64)
+extern "C" __attribute__((visibility("default"))) int ttl_diag_clock_stamps_huge(void* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_huge_stamps), sizeof(TtlClockStamp) * TTL_STAMP_SLOTS);
+}
+#endif
 
 bool gemm_huge_applicable(GemmEpi epi, const GemmArgs& a) {
     // TTL_GEMM_HUGE: 0 = off (everything on gemm_big.hip), 1 = q/k/v and fc1, 2 = q/k/v-shaped (EPI_OP) only (default), 3 = fc1 only.

@@ -196,6 +196,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
 }
 #else
 __device__ __forceinline__ int wg_u(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+// Byte offset of row `row`, byte `b` of the S chunk image [256][R] (rows of 2 R bytes).  A fragment read (ds_read_tr16_b64) touches, per
+// half-wave, 8 bytes x 4 in each of the rows {0-3, 8-11} (+4 for the second read, +16 for the other half-wave) of a 32-row group: with
+// plain rows, rows r and r + 8 lie 256 B (R = 16) or 512 B (R = 32) apart — the same 64 banks, a 2-way conflict on every S read
+// (rocprofv3 SQ_LDS_BANK_CONFLICT: 1.5e5 per launch, profiles/r05_pmc_summary_fp16.txt).  Rows with bit 3 set therefore swap the halves
+// of their 256-B window (R = 16: address bit 7) / of their own 64-B row (R = 32: bit 5); the staging stores apply the same map.
+template <int R>
+__device__ __forceinline__ int wg_s_off(int row, int b) { return (row * (R * 2) + b) ^ (((row >> 3) & 1) << (R == 16 ? 7 : 5)); }
 
 template <int R>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, int D, float* __restrict__ partial, int nch, int prod0) {
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
 #pragma unroll
         for (int j = 0; j < R / 8; ++j) {
             const int q = tid + 256 * j, r = q / (R / 8), c = q - r * (R / 8);
-            *(u32x4*)(sS + r * (R * 2) + (c << 4)) = (m0 + r < M) ? sv[j] : zero;
+            *(u32x4*)(sS + wg_s_off<R>(r, c << 4)) = (m0 + r < M) ? sv[j] : zero;
         }
     }
     __syncthreads();
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradList L, int M, in
         opx8 sf[R / 16], gf[2];
 #pragma unroll
         for (int a = 0; a < R / 16; ++a) {
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + rlo * (R * 2) + (a * 16 + 4 * tp) * 2));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + rhi * (R * 2) + (a * 16 + 4 * tp) * 2));
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + wg_s_off<R>(rlo, (a * 16 + 4 * tp) * 2)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sS + wg_s_off<R>(rhi, (a * 16 + 4 * tp) * 2)));
             s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             sf[a] = __builtin_bit_cast(opx8, v);
         }

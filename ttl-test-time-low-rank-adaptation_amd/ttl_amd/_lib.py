@@ -99,6 +99,7 @@ SIGNATURES = {
     "ttl_vit_backward_lora": (_I, [_P, _P, _I, _P]),
     "ttl_vit_backward_lora_selected": (_I, [_P, _P, _I, _P, _I, _P]),
     "ttl_ctx_set_concurrency": (_I, [_P, _I]),
+    "ttl_ctx_backward_prescaled": (_I, [_P, _I]),
     "ttl_adamw_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P, _P]),
     "ttl_lora_reset": (_I, [_P, _P, _P, _P, _Z, _P]),
     "ttl_scaler_config": (_I, [_P, _I, _F, _F, _F, _I]),

@@ -100,7 +100,8 @@ class _VitLogitsFn(torch.autograd.Function):
                            "model (two contexts hold at most two pending backwards; call backward earlier or run the "
                            "other forwards under torch.no_grad())")
         ctx.engine._pending_gen = None
-        flat = ctx.engine.backward(dlogits.contiguous())
+        # (dlogits comes from torch's graph: if a GradScaler scaled the loss it is in there already — the context's own scale stays out)
+        flat = ctx.engine.backward_prescaled(dlogits.contiguous())
         outs, off = [], 0
         for s in ctx.shapes:
             n = int(np.prod(s))
@@ -140,6 +141,9 @@ class _TextModeEngine:
 
     def backward(self, dlogits, selection=None):      # (text mode: every prompt's features carry gradient, nothing to restrict)
         return self.txt.backward(dlogits)
+
+    def backward_prescaled(self, dlogits):
+        return self.txt.backward_prescaled(dlogits)
 
     def bind_lora(self, flat):
         self.txt.bind_lora(flat)

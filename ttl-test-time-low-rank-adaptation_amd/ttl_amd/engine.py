@@ -172,6 +172,18 @@ class TTLEngine:
                 self._check(self.lib.ttl_vit_backward_lora(self._h, _ptr(d), d.shape[0], _stream()))
         return self.grads
 
+    def backward_prescaled(self, dlogits: torch.Tensor):
+        """The backward of an AUTOGRAD node (custom_clip._VitLogitsFn): ``dlogits`` is whatever torch hands down — already multiplied
+        by the caller's GradScaler factor when the reference's `scaler.scale(loss).backward()` runs (deyo.py:185) — so the context's
+        own loss scale must not be applied on top; the gradients come back scaled like ``dlogits`` (torch's scaler.step unscales them).
+        include/ttl_hip.h ttl_ctx_backward_prescaled."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ttl_ctx_backward_prescaled(self._h, 1))
+        try:
+            return self.backward(dlogits)
+        finally:
+            self._check(self.lib.ttl_ctx_backward_prescaled(self._h, 0))
+
     def entropy_select_loss(self, logits, mode, rho=0.1, thresh=None, margin=0.4, reweight=1.0, keep=None):
         """-> dict(H [N], idx int64 [N] (first n valid), n int32 [1], loss [1], dlogits [N,K]); all device tensors.
         keep: optional uint8/bool [N] second-stage filter (PLPD): selected views with keep == 0 are dropped."""
