@@ -481,9 +481,10 @@ def main():
             return {"logits_max_rel": r["logits_max_rel"], "adapted_logits_max_rel": r["adapted_logits_max_rel"], "grad_max_rel": r["grad_max_rel"],
                     "lora_weights_rel_frobenius": r["lora_weights_rel_frobenius"], "mask_exact": r["mask_exact"], "top1_equal": r["top1_equal"],
                     "selection_mask_and_logits_within_tolerance": bool(m["selection_mask"] and m["logits"])}
-        for p in legs + ["strict"]:     # (strict: the test-only fp32 build on the same fixtures, never timed)
+        # (N > 1: the other ranks wait at the first barrier while rank 0 checks parity — the deciding fixtures on the timed builds only)
+        for p in legs + (["strict"] if world == 1 else []):     # (strict: the test-only fp32 build on the same fixtures, never timed)
             per = {}
-            for fx in PARITY_DECIDE + PARITY_OTHERS:
+            for fx in PARITY_DECIDE + (PARITY_OTHERS if world == 1 else ()):
                 try:
                     r = parity_check(p, fx)
                 except Exception as e:      # a missing fixture must not hide the timing; it is reported instead
@@ -495,7 +496,7 @@ def main():
             parity[p]["fixtures"] = per
             parity[p]["fixtures_deciding"] = list(PARITY_DECIDE)
             parity[p]["conforms_on_every_deciding_fixture"] = all(ok(fx) for fx in PARITY_DECIDE)
-            parity[p]["fixtures_outside_tolerance"] = [fx for fx in PARITY_DECIDE + PARITY_OTHERS if not ok(fx)]
+            parity[p]["fixtures_outside_tolerance"] = [fx for fx in per if not ok(fx)]
 
     def conforms(p):
         return bool(parity.get(p, {}).get("conforms_on_every_deciding_fixture"))

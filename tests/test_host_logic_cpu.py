@@ -282,3 +282,32 @@ def test_resume_tag_names_every_result_affecting_argument():
                    filter_plpd=1, plpd_threshold=0.3, aug_type="occ", patch_len=4, occlusion_size=64, row_start=0, column_start=8)
     for k, v in changed.items():
         assert resume_tag(argparse.Namespace(**{**vars(a), k: v})) != base, k
+
+
+def test_plpd_permutations_are_the_references_draws():
+    """deyo.draw_plpd_perms makes the reference's RNG calls — torch.argsort(torch.rand(B, P), dim=-1) per 'patch' step (deyo.py:127),
+    torch.randperm(S * S) per 'pixel' step (deyo.py:133) — in the reference's order on the global CPU generator, although it draws int32
+    on one intra-op thread and (in the pipeline) straight into a pinned staging buffer; the thread count is restored; 'occ' draws nothing."""
+    import torch
+    from ttl_amd import deyo as D
+    nt = torch.get_num_threads()
+    for seed in (0, 7):
+        torch.manual_seed(seed)
+        want = [torch.argsort(torch.rand(6, 16), dim=-1) for _ in range(3)]
+        after = torch.rand(1)
+        torch.manual_seed(seed)
+        got = D.draw_plpd_perms(dict(aug_type="patch", patch_len=4), 3, 6, 32, "cpu")
+        assert got.dtype == torch.int32 and tuple(got.shape) == (3, 6, 16) and torch.equal(got.long(), torch.stack(want))
+        assert torch.equal(torch.rand(1), after)                 # the generator is where the reference's calls would have left it
+        torch.manual_seed(seed)
+        want = [torch.randperm(224 * 224) for _ in range(2)]
+        after = torch.rand(1)
+        torch.manual_seed(seed)
+        out = torch.empty((2, 224 * 224), dtype=torch.int32)
+        got = D.draw_plpd_perms(dict(aug_type="pixel", patch_len=4), 2, 64, 224, "cpu", out=out)
+        assert got is out and torch.equal(out.long(), torch.stack(want)) and torch.equal(torch.rand(1), after)
+    assert D.draw_plpd_perms(dict(aug_type="occ", patch_len=4), 1, 8, 32, "cpu") is None
+    assert D.plpd_perm_shape(dict(aug_type="occ", patch_len=4), 1, 8, 32) is None
+    assert torch.get_num_threads() == nt
+    with pytest.raises(ValueError):
+        D.draw_plpd_perms(dict(aug_type="pixel", patch_len=4), 1, 8, 32, "cpu", out=torch.empty((1, 10), dtype=torch.int32))

@@ -1,14 +1,21 @@
 #!/bin/bash
 # PMC evidence of a round (separate passes: the MI355X guide's HBM/rocprofv3 section; never combined with trace domains):
-#   bash tools/collect_pmc.sh r05 [fp16|bf16]   -> gpurun_out/r05_fp16/pmc_*/ ; summary + traffic json beside them
+#   bash tools/collect_pmc.sh r06 [fp16|bf16] [traffic-only]   -> gpurun_out/r05_fp16/pmc_*/ ; summary + traffic json beside them
 # (second argument: the operand build tools/quick_bench.py runs, through TTL_PRECISION; default fp16 = the headline build)
-R=${1:-r05}
+R=${1:-r06}
 P=${2:-fp16}
 export TTL_PRECISION=$P
 export TTL_CONCURRENCY=3      # quick_bench.py runs one stream: with the tile choices of the three-stream timed region (ttl_ctx_set_concurrency)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${R}_$P; mkdir -p $O
 # every pass under its own timeout: a counter set the hardware cannot collect makes rocprofv3 abort and then hang
 pass() { name=$1; shift; timeout 200 rocprofv3 --pmc "$@" -d $O/pmc_$name -o $name --output-format csv -- python3 tools/quick_bench.py > $O/pmc_$name.log 2>&1; echo "pass $name rc=$?"; }
+if [ "$3" = traffic-only ]; then      # FETCH_SIZE / WRITE_SIZE passes alone -> gemm_traffic.json (the bf16 leg's figure in the bench line)
+  pass fetch FETCH_SIZE
+  pass write WRITE_SIZE
+  python3 tools/pmc_summary.py $O/pmc_summary.txt $O/gemm_traffic.json $(find $O/pmc_fetch $O/pmc_write -name "*counter_collection.csv") > $O/pmc_summary.stdout 2>&1
+  head -c 2000 $O/pmc_summary.txt
+  exit 0
+fi
 pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

@@ -4,19 +4,20 @@
 # rocprofv3 --kernel-trace SERIALISES kernels, so its durations are "the kernel alone on the chip" whatever --streams is: ONE
 # kernel-stats file is collected (plain enqueues, one stream); the 3-episodes-in-flight regime exists only in bench.py's own
 # event timing (roofline.episodes_in_flight) and in the end-to-end rate.
-#   bash tools/collect_profiles.sh r05 [fp16|bf16]      (second argument: the operand build every profiled run uses; default fp16 =
+#   bash tools/collect_profiles.sh r06 [fp16|bf16]      (second argument: the operand build every profiled run uses; default fp16 =
 #   the headline build since round 4.  Output directory gpurun_out/<round>_<build>/)
-R=${1:-r05}
+R=${1:-r06}
 P=${2:-fp16}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${R}_$P; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-python3 bench.py --streams 1 --no-cpu-baseline --no-parity --precision $P > $O/bench_streams1.json 2>> $O/bench.err
-Q="--no-cpu-baseline --no-parity --precision $P"
-# (TTL_CONCURRENCY=3: one stream, serialised by the profiler, with the tile choices of the three-stream timed region)
+python3 bench.py --streams 1 --no-cpu-baseline --no-parity --precision $P --sustain-seconds 0 > $O/bench_streams1.json 2>> $O/bench.err
+Q="--no-cpu-baseline --no-parity --precision $P --sustain-seconds 0"
+# (TTL_CONCURRENCY=3: one stream, serialised by the profiler, with the tile choices of the three-stream timed region; a run-time
+#  switch off its default needs --variant-env since round 6)
 export TTL_CONCURRENCY=3
-rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 $Q > $O/prof1.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof1 -o p1 --output-format csv -- python3 bench.py --steps 60 --warmup 10 --repeats 1 --streams 1 --graph 0 $Q --variant-env > $O/prof1.log 2>&1
 unset TTL_CONCURRENCY
 python3 bench.py --lora-targets qkvo $Q > $O/bench_qkvo.json 2>> $O/bench.err
 python3 bench.py --graph 0 $Q > $O/bench_graph0.json 2>> $O/bench.err

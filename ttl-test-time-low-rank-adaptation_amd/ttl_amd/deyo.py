@@ -125,18 +125,44 @@ def plpd_spec(args):
                 row_start=int(getattr(args, "row_start", 0) or 0), column_start=int(getattr(args, "column_start", 0) or 0))
 
 
-def draw_plpd_perms(spec, n_updates, n_candidates, size, device):
+def plpd_perm_shape(spec, n_updates, n_candidates, size):
+    """Shape of the int32 permutation tensor of ``n_updates`` PLPD steps (None: 'occ' draws nothing)."""
+    if spec["aug_type"] == "patch":
+        return (n_updates, n_candidates, spec["patch_len"] ** 2)
+    if spec["aug_type"] == "pixel":
+        return (n_updates, size * size)
+    return None
+
+
+def draw_plpd_perms(spec, n_updates, n_candidates, size, device, out=None):
     """The random permutations of ``n_updates`` PLPD steps, drawn from torch's CPU generator in the reference's call order —
     'patch': torch.argsort(torch.rand(B, patch_len**2), dim=-1) per step (deyo.py:127), 'pixel': torch.randperm(S*S) per step
-    (deyo.py:133) — as ONE device int32 tensor [n_updates, ...]; 'occ' draws nothing (None)."""
-    if spec["aug_type"] == "patch":
-        P = spec["patch_len"] ** 2
-        perms = [torch.argsort(torch.rand(n_candidates, P), dim=-1) for _ in range(n_updates)]
-    elif spec["aug_type"] == "pixel":
-        perms = [torch.randperm(size * size) for _ in range(n_updates)]
-    else:
+    (deyo.py:133) — as ONE int32 tensor [n_updates, ...]; 'occ' draws nothing (None).  ``out``: a host int32 tensor of
+    ``plpd_perm_shape`` (the pipeline's pinned staging buffer) to draw into; otherwise the result is moved to ``device``.
+    The draws are the reference's (torch.randperm fills an int32 tensor with the SAME permutation it would fill an int64 one with:
+    ATen's randperm_cpu draws `generator->random() % (n - i)` whatever the dtype; tests/test_host_logic_cpu.py pins it) but they are
+    made on ONE intra-op thread: every draw is a sequential algorithm, and on a host whose CPU quota is far below its core count (the
+    GPU boxes: 256 logical CPUs, quota 16, torch defaults to 128 threads) each OpenMP region around it costs milliseconds —
+    10.4 ms per image for the 50 176-entry 'pixel' permutation before, 0.2 ms now (profiles/r06_experiments.txt r06d)."""
+    shape = plpd_perm_shape(spec, n_updates, n_candidates, size)
+    if shape is None:
         return None
-    return torch.stack(perms).to(dtype=torch.int32).contiguous().to(device, non_blocking=True)
+    if out is not None and (tuple(out.shape) != shape or out.dtype != torch.int32 or out.is_cuda or not out.is_contiguous()):
+        raise ValueError(f"out must be a contiguous host int32 tensor of shape {shape}")
+    buf = out if out is not None else torch.empty(shape, dtype=torch.int32)
+    nt = torch.get_num_threads()
+    try:
+        if nt > 1:
+            torch.set_num_threads(1)
+        for j in range(n_updates):
+            if spec["aug_type"] == "patch":
+                buf[j].copy_(torch.argsort(torch.rand(n_candidates, shape[2]), dim=-1))
+            else:
+                torch.randperm(shape[1], dtype=torch.int32, out=buf[j])
+    finally:
+        if nt > 1:
+            torch.set_num_threads(nt)
+    return buf if out is not None else buf.to(device, non_blocking=True)
 
 
 def plpd_candidates(args, n_views, n_classes):

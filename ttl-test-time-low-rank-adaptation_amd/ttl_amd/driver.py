@@ -484,20 +484,21 @@ class EpisodePipeline:
             if sl.get("aux_classes") != self._text_version:
                 aux.set_text_features(self._text_features, self._logit_scale)
                 sl["aux_classes"] = self._text_version
-        perm = draw_plpd_perms(spec, n_updates, nc, views.shape[-1], "cpu")
+        from .deyo import plpd_perm_shape
+        shape = plpd_perm_shape(spec, n_updates, nc, views.shape[-1])
         buf = None
-        if perm is not None:
+        if shape is not None:
             buf = sl.get("permbuf")
-            if buf is None or buf.shape != perm.shape:
-                buf = sl["permbuf"] = torch.empty(perm.shape, dtype=torch.int32, device=views.device)
-                sl["permpin"] = [torch.empty(perm.shape, dtype=torch.int32).pin_memory() for _ in range(2)]     # (pinning per image costs ms)
+            if buf is None or tuple(buf.shape) != shape:
+                buf = sl["permbuf"] = torch.empty(shape, dtype=torch.int32, device=views.device)
+                sl["permpin"] = [torch.empty(shape, dtype=torch.int32).pin_memory() for _ in range(2)]     # (pinning per image costs ms)
                 sl["permev"] = [None, None]
                 sl["permi"] = 0
                 sl["gkey"] = None                       # a captured graph holds the old buffer's address
             k = sl["permi"] = sl["permi"] ^ 1            # two staging buffers: the copy of image i-2 of this slot has long completed
             if sl["permev"][k] is not None:
                 sl["permev"][k].synchronize()
-            sl["permpin"][k].copy_(perm)
+            draw_plpd_perms(spec, n_updates, nc, views.shape[-1], "cpu", out=sl["permpin"][k])      # straight into the pinned staging buffer
             buf.copy_(sl["permpin"][k], non_blocking=True)       # on the slot's stream, ahead of the episode
             sl["permev"][k] = torch.cuda.Event()
             sl["permev"][k].record()
