@@ -772,6 +772,24 @@ def main():
                         "regime", "rocprofv3 --pmc, streams=1, separate FETCH_SIZE / WRITE_SIZE passes")
                 except Exception:
                     pass
+        # the clock the chip holds inside the dominant kernels' K loops (diagnostic -DTTL_CLOCK_STAMPS builds, tools/r06_clock_stamps.py): a
+        # STATIC read of the committed measurement — it turns "frac of 2.5 PF (= 2.4 GHz)" into a fraction of what the silicon clocks under this load
+        try:
+            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_inkernel_clock.txt")))[-1]
+            rows = {}
+            for line in open(src):
+                m = __import__("re").search(r"^(.*?)\s+([0-9.]+) us/launch =\s+([0-9.]+) TFLOP/s .*clock whole kernel\s+([0-9.]+) MHz.*K loop\s+([0-9.]+) MHz,\s+([0-9.]+) cycles for (\d+) K-steps", line)
+                if m:
+                    rows[m.group(1).strip()] = {"us": float(m.group(2)), "tflops": float(m.group(3)), "clock_whole_kernel_mhz": float(m.group(4)),
+                                                "clock_k_loop_mhz": float(m.group(5)), "cycles_per_k_step": round(float(m.group(6)) / int(m.group(7)))}
+            if rows:
+                for p in legs:
+                    if p in roofs:
+                        roofs[p]["inkernel_clock"] = {"static": True, "source": "profiles/" + os.path.basename(src), "peak_assumes_mhz": 2400, "launches": rows,
+                                                      "note": "fp16 operands, random data, >= 2.5 s of back-to-back launches; gemm_huge's K loop is 91-93 % MFMA-busy at "
+                                                              "1.41-1.50 GHz: 0.91 of the MFMA peak of the clock the chip holds, 0.57 of the 2.4-GHz peak"}
+        except Exception:
+            pass
     for p in legs:
         pipes[p].close()
 
