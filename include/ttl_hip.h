@@ -1,5 +1,7 @@
 /*
- * ttl_hip.h — C ABI of libttl_hip.so: TTL's per-sample hot path on MI355X (gfx950).
+ * ttl_hip.h — C ABI of libttl_hip_fp16.so (fp16 operands: the build the Python surface loads by default) and of its sibling builds of the
+ * same sources (libttl_hip.so: bf16 operands; libttl_hip_strict.so, libttl_hip_fp16_exp.so: tests / tools): TTL's per-sample hot path on
+ * MI355X (gfx950).
  *
  * The reference is pure Python on torch/transformers/peft; the "FFI" a maintainer binds is
  * ctypes.  Each entry point below names the reference code it replaces
