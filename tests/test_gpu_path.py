@@ -705,6 +705,41 @@ def test_head_major_qkv_changes_addresses_only(monkeypatch, precision, targets):
     assert np.abs(a[4]).max() > 0
 
 
+@pytest.mark.parametrize("name", ["tiny_all_deyo", "b16_n8_k10", "b16_n64_k200_ent0"])
+def test_embedding_pass_equals_the_three_launches(monkeypatch, name):
+    """Round 6: the CLS rows (modeling_clip.py:187-196), the pre-LayerNorm (:854) and LayerNorm 1 of encoder layer 0 (:359) are ONE pass
+    over the embedded rows (elementwise.hip embed_ln2_kernel) instead of three launches.  Every sum is taken in the order the two
+    LayerNorm kernels take it: logits, saved activations, gradients (tiny_all: layer 0 itself is trained, its LayerNorm-1 statistics
+    come out of the fused pass), adapters and the adapted prediction are BITWISE equal to the three-launch sequence
+    (TTL_EMBED_FUSED=0, a closed switch: experiments build)."""
+    import os
+    import subprocess
+    import sys
+    res = {}
+    for fused in ("1", "0"):          # (the switch is read once per process: each arm runs in a child process)
+        code = (
+            "import sys, os, numpy as np, torch\n"
+            f"sys.path[:0] = [{repr(os.path.dirname(os.path.abspath(__file__)))}, {repr(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ttl-test-time-low-rank-adaptation_amd'))}, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))}]\n"
+            "from helpers import load_case, episode_kwargs\n"
+            "from test_gpu_path import make_engine\n"
+            f"g, cfg, W, x, lora0, tf = load_case({name!r}); kw = episode_kwargs(g)\n"
+            "eng, flat, names = make_engine(cfg, W, lora0, tf, x.shape[0], precision='experiments')\n"
+            "xd = torch.from_numpy(x).cuda()\n"
+            "z = eng.forward(xd, save=True).clone()\n"
+            "snap, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)\n"
+            "l1, l0 = eng.episode(xd, snap, m, v, n_updates=kw['n_updates'], objective=kw['objective'], mode=1 if kw['mode'] == 'topk' else 0, rho=kw['rho'], margin=kw['margin'], lr=kw['lr'], want_logits0=True)\n"
+            "torch.cuda.synchronize()\n"
+            "np.savez(sys.argv[1], z=z.cpu().numpy(), l0=l0.cpu().numpy(), l1=l1.cpu().numpy(), grads=eng.grads.cpu().numpy(), flat=flat.cpu().numpy())\n")
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"embed_fused_{name}_{fused}_{os.getpid()}.npz")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, TTL_EMBED_FUSED=fused), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[fused] = dict(np.load(out))
+        os.remove(out)
+    for k in res["1"]:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert np.abs(res["1"]["grads"]).max() > 0 and np.isfinite(res["1"]["l1"]).all()
+
+
 def test_shared_weight_images_give_the_same_bits():
     """ttl_ctx_create_shared: a second context on the SAME frozen weight images (one model per process in the reference,
     ttl.py:178-179) computes bit for bit what a context with private copies computes — with both contexts alive and

@@ -785,16 +785,19 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
     if (!images_fresh && (rc = lora_refresh(c, s))) return rc;
     float* h = c->h;
     bool pooled_now = false;
+    bool ln1_of_layer0_done = false;     // image tower, from_layer == 0: LayerNorm 1 of layer 0 comes out of the embedding pass
     if (from_layer == 0 && c->text) {
         Prof p(c, 3, s);
         HIP_TRY(launch_text_embed(c->ids, c->tok, c->pos, c->h, M, T, D, s));   // no pre-LN in the text tower
         c->stream_views = n;
     } else if (from_layer == 0) {
-        // patch embedding: im2col -> GEMM (+pos) ; CLS rows
+        // patch embedding: im2col -> GEMM (+pos); the CLS rows, the pre-LayerNorm and LayerNorm 1 of layer 0 are ONE pass behind it
+        // (TTL_EMBED_FUSED=0, experiments build only: the three launches of rounds 1-5 — the bit-identity test's other arm)
+        static const int embed_fused = TTL_EXPERIMENT("TTL_EMBED_FUSED", 1);
         {
             Prof p(c, 3, s);
             HIP_TRY(launch_im2col(x, c->patches, n, c->S, c->P, c->Kp, s));
-            HIP_TRY(launch_cls_rows(c->h, c->cls, c->pos, n, T, D, s));
+            if (!embed_fused) HIP_TRY(launch_cls_rows(c->h, c->cls, c->pos, n, T, D, s));
         }
         {
             GemmArgs a = {};
@@ -802,9 +805,18 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
             a.C = c->h; a.ldc = D; a.pos = c->pos; a.G2 = c->G2; a.T = T;
             if ((rc = gemm(c, EPI_PATCH, a, s))) return rc;
         }
-        {
+        {   // (round 6: was launch_cls_rows + launch_layernorm in place + layer 0's launch_layernorm — bit-identical, two launches and two passes
+            //  over the embedded rows fewer; the layer loop below skips layer 0's LayerNorm 1)
             Prof p(c, 3, s);
-            HIP_TRY(launch_layernorm(h, D, c->preg, c->preb, h, nullptr, 0, nullptr, nullptr, M, D, c->c.ln_eps, s));
+            Layer& l0 = c->layers[0];
+            const bool tr0 = l0.trained && c->lora_p, sv0 = tr0 && save;
+            if (embed_fused) {
+                HIP_TRY(launch_embed_layernorms(h, c->cls, c->pos, T, c->preg, c->preb, l0.ln1g, l0.ln1b, tr0 ? l0.x1ext : c->x1, tr0 ? c->ldx : D,
+                                                sv0 ? l0.mu1 : nullptr, sv0 ? l0.rs1 : nullptr, M, D, c->c.ln_eps, s));
+                ln1_of_layer0_done = true;
+            } else {
+                HIP_TRY(launch_layernorm(h, D, c->preg, c->preb, h, nullptr, 0, nullptr, nullptr, M, D, c->c.ln_eps, s));
+            }
         }
         c->stream_views = n;
     } else if (from_layer != c->c.layer_lo || n > c->stream_views) {
@@ -824,7 +836,7 @@ static int forward_impl(ttl_ctx* c, const float* x, int n, int save, int from_la
         const int ldat = tr ? l.ldat : D;              // (row pitch of att: K-extension columns for an out_proj adapter)
         const bool lo_qkv = lo && c->nqkv > 0, lo_o = lo && c->has_o;
         float* h_in = h;  // trained layers write h_mid / h_out to fresh buffers, so h_in survives for LN1 backward
-        {
+        if (!(i == 0 && ln1_of_layer0_done)) {
             Prof p(c, 3, s);
             HIP_TRY(launch_layernorm(h_in, D, l.ln1g, l.ln1b, nullptr, x1, ldx1, sv ? l.mu1 : nullptr, sv ? l.rs1 : nullptr, M, D, c->c.ln_eps, s));
         }

@@ -136,6 +136,14 @@ hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, 
     mat_w(h, (long long)(n - 1) * T + 1, D, D, 4);
     return hipSuccess;
 }
+hipError_t launch_embed_layernorms(float* h, const float* cls, const float* pos, int, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, op_t* y16, int ld16, float* mean, float* rstd, int rows, int D, float, hipStream_t) {
+    span_r(cls, (size_t)D * 4); span_r(pos, (size_t)D * 4);
+    for (const float* p : {g0, b0, g1, b1}) span_r(p, (size_t)D * 4);
+    mat_r(h, rows, D, D, 4); mat_w(h, rows, D, D, 4); mat_w(y16, rows, D, ld16, 2);
+    span_w(mean, (size_t)rows * 4); span_w(rstd, (size_t)rows * 4);
+    return hipSuccess;
+}
 hipError_t launch_layernorm(const float* x, long long row_stride, const float* gamma, const float* beta, float* y_f32, op_t* y_bf16,
                             int ld_bf16, float* mean, float* rstd, int rows, int D, float, hipStream_t, const int* rowmap) {
     if (rowmap) { span_r(rowmap, (size_t)rows * 4); for (int r : {0, rows - 1}) mat_r(x + (size_t)rowmap[r] * row_stride, 1, D, D, 4); }

@@ -433,6 +433,74 @@ hipError_t launch_im2col(const float* x, op_t* patches, int n, int S, int P, int
     return hipGetLastError();
 }
 
+// ---- episode start, image tower: CLS rows + pre-LayerNorm + LayerNorm 1 of layer 0 in ONE pass over the embedded rows (round 6).
+// HF modeling_clip.py:187-196 (class embedding + position embedding), :854 (pre_layrnorm) and :359 (layer_norm1 of encoder layer 0) via
+// clip/custom_clip.py:62-71 of the reference.  Three launches before (cls_rows_kernel, ln_fwd_kernel with an fp32 output in place,
+// ln_fwd_persist_kernel): the rows were written, read, written, read again.  One wave per row; lane l owns float4 chunks l, l + 64, ...
+// and every sum is taken in the order the two LayerNorm kernels take it, so h, x1 and the statistics are BIT-identical to the
+// three-launch sequence (tests/test_gpu_kernels.py::test_embed_layernorms_equal_the_three_launches).
+//   row r of image r / T: x = (r % T == 0) ? cls + pos[0] : h[r] (the patch rows the EPI_PATCH GEMM wrote, position embedding included)
+//   y = LN(x; g0, b0) -> h[r] (fp32: the residual stream);   x1[r] = LN(y; g1, b1) in the operand type (+ mean / rstd of that second LayerNorm)
+__global__ __launch_bounds__(256) void embed_ln2_kernel(float* __restrict__ h, const float* __restrict__ cls, const float* __restrict__ pos, int T,
+                                                        const float* __restrict__ g0, const float* __restrict__ b0,
+                                                        const float* __restrict__ g1, const float* __restrict__ b1,
+                                                        op_t* __restrict__ y16, int ld16, float* __restrict__ mean, float* __restrict__ rstd,
+                                                        int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nch = D >> 2;
+    const bool is_cls = (row % T) == 0;
+    float4 v[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            if (is_cls) {
+                const float4 a = *(const float4*)(cls + 4 * c), p = *(const float4*)(pos + 4 * c);
+                v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            } else v[i] = *(const float4*)(h + (size_t)row * D + 4 * c);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* gamma = pass ? g1 : g0;
+        const float* beta = pass ? b1 : b0;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);      // (zero beyond nch)
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            if (lane + 64 * i < nch) {
+                const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (pass && lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+                const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
+                const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
+                if (pass) st_op4(y16 + (size_t)row * ld16 + 4 * c, o0, o1, o2, o3);
+                else { *(float4*)(h + (size_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3); v[i] = make_float4(o0, o1, o2, o3); }
+            }
+        }
+    }
+}
+
+hipError_t launch_embed_layernorms(float* h, const float* cls, const float* pos, int T, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, op_t* y16, int ld16, float* mean, float* rstd, int rows, int D, float eps, hipStream_t s) {
+    if (D % 4 || D > 256 * LN_MAXC || T < 1 || rows < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_ln2_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, cls, pos, T, g0, b0, g1, b1, y16, ld16, mean, rstd, rows, D, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, int T, int D, hipStream_t s) {
     hipLaunchKernelGGL(cls_rows_kernel, dim3((n * D + 255) / 256), dim3(256), 0, s, h, cls, pos, n, T, D);
     return hipGetLastError();

@@ -100,6 +100,11 @@ hipError_t launch_cast_rows_f32_op(const float* src, int rows, int cols, op_t* d
 hipError_t launch_im2col(const float* x, op_t* patches, int n, int S, int P, int Kp, hipStream_t s);
 // h[n*T + 0][:] = cls + pos[0]
 hipError_t launch_cls_rows(float* h, const float* cls, const float* pos, int n, int T, int D, hipStream_t s);
+// Episode start of the image tower in one pass: h[r] = LN(r % T == 0 ? cls + pos[0] : h[r]; g0, b0) (fp32, in place) and
+// y16[r] = LN(h[r]; g1, b1) in the operand type (+ mean / rstd of the second LayerNorm); bit-identical to launch_cls_rows +
+// launch_layernorm(in place) + launch_layernorm
+hipError_t launch_embed_layernorms(float* h, const float* cls, const float* pos, int T, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, op_t* y16, int ld16, float* mean, float* rstd, int rows, int D, float eps, hipStream_t s);
 // LayerNorm over rows of fp32 x [rows, D].  y_f32 (ld D) and/or y_bf16 (ld ld_bf16) outputs;
 // mean/rstd optional saves.  row_stride: distance (elements) between consecutive input rows
 // (T*D to pick CLS rows).
